@@ -1,0 +1,142 @@
+/*
+ * kmpgpu.h -- C-ABI of the MI355X (gfx950) KMP match-count hot path.
+ *
+ * The reference has no FFI: its hot path is the loop
+ *     string_count[i] += kmp_matcher(array_of_payloads[k], array_of_strings[i], prefix_array[i]);
+ * at serial.c:153-155 (= openmp_data.c:157-175, mpi_dumping.c:198-200) with kmp_matcher at
+ * serial.c:190-215 and kmp_prefix at serial.c:217-238.  A maintainer replaces that loop by the
+ * calls below (INTEGRATION.md shows the patch).  Library:
+ * multithreading_string_matching_amd/lib/libkmpgpu.so (hipcc, --offload-arch=gfx950).
+ *
+ * Semantics (bit-exact with compiled serial.c): for payload k of length L_k,
+ * E_k = min(L_k, index of its first 0x00); count[i] = sum over k of the number of start offsets
+ * s with s + m_i <= E_k and payload_k[s : s+m_i] == pattern_i (overlapping starts all count).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 or a negative KMPGPU_E*
+ * code and never exits; kmpgpu_last_error() gives the text.  One context drives one GPU (one
+ * process per GPU; multi-GPU sums the per-context counts, see kmpgpu_counts_device).  A context
+ * is not thread-safe.  Host buffers passed in are borrowed for the call; device buffers created
+ * by the context are owned by it.
+ */
+#ifndef KMPGPU_H
+#define KMPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "kmp_synth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMPGPU_OK         0
+#define KMPGPU_EHIP      -1   /* a HIP runtime call failed (no device, out of memory ...)  */
+#define KMPGPU_EINVAL    -2   /* bad argument / layout contract violated                    */
+#define KMPGPU_ESTATE    -3   /* call order: patterns or arena not set                      */
+#define KMPGPU_ENOMEM    -4
+
+#define KMPGPU_MAX_PATTERN_LEN 99      /* serial.c:64 */
+#define KMPGPU_SLOT_ALIGN      16
+
+typedef struct kmpgpu_ctx kmpgpu_ctx;
+
+/* Timing of the last kmpgpu_scan / kmpgpu_load_arena on this context (HIP events on the
+ * context's stream). */
+typedef struct kmpgpu_timing {
+    double   h2d_ms;          /* arena + index upload (kmpgpu_load_arena)                  */
+    double   kernel_ms;       /* scan kernel(s) + partial-count reduce                     */
+    double   d2h_ms;          /* counts download                                           */
+    uint32_t launches;        /* scan-kernel launches in the last scan                     */
+    uint32_t grid_blocks;     /* blocks per launch (x dimension)                           */
+} kmpgpu_timing;
+
+/* One reported match (kmpgpu_scan_offsets).  Not in the reference, which prints counts only
+ * (serial.c:163-166); BASELINE north_star asks for offsets. */
+typedef struct kmpgpu_match {
+    uint64_t packet;          /* payload index in the arena                                */
+    uint32_t offset;          /* start offset inside the payload                           */
+    uint32_t pattern;         /* pattern index (file order)                                */
+} kmpgpu_match;
+
+/* Option keys for kmpgpu_set_option. */
+#define KMPGPU_OPT_MODE          1   /* 0 auto (filter + KMP verify), 1 KMP automaton only */
+#define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this (default 8)           */
+#define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6 (default 4) */
+#define KMPGPU_OPT_FUSED         4   /* 1 = one pass for all patterns when available       */
+
+const char *kmpgpu_last_error(void);
+int  kmpgpu_device_count(void);                        /* >= 0, or KMPGPU_EHIP                */
+
+/* Create / destroy the context for one device.  Replaces nothing in the reference (its state
+ * lives in main()'s locals, serial.c:99-101,148). */
+int  kmpgpu_init(kmpgpu_ctx **ctx, int device);
+void kmpgpu_destroy(kmpgpu_ctx *ctx);
+
+/* Launch on a caller-owned HIP stream (hipStream_t, e.g. torch's current stream); NULL returns
+ * to the context's own stream. */
+int  kmpgpu_set_stream(kmpgpu_ctx *ctx, void *hip_stream);
+int  kmpgpu_set_option(kmpgpu_ctx *ctx, int key, int64_t value);
+
+/* Pinned host memory for the arena (north_star: "pinned contiguous arena"). */
+void *kmpgpu_host_alloc(size_t bytes);
+void  kmpgpu_host_free(void *p);
+
+/* Replaces array_of_strings + prefix_array construction, serial.c:148-152 (kmp_prefix for every
+ * pattern): copies the patterns, builds the failure tables on the host, uploads both.
+ * 1 <= pat_len[i] <= 99, no 0x00 inside a pattern (fscanf("%s") + strlen cannot produce one). */
+int  kmpgpu_set_patterns(kmpgpu_ctx *ctx, const uint8_t *const *pat, const uint32_t *pat_len, uint32_t n_pat);
+
+/* Replaces array_of_payloads, serial.c:99,124-136: upload a host arena + index (H2D copy,
+ * device copy owned by the context).  Contract: pkt_off[k] % 16 == 0 and
+ * pkt_off[k] + max(16, round_up(pkt_len[k], 16)) <= arena_bytes for every k (checked): every
+ * payload, also an empty one, owns at least one readable 16-byte slot. */
+int  kmpgpu_load_arena(kmpgpu_ctx *ctx, const uint8_t *arena, uint64_t arena_bytes,
+                       const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n_pkts);
+
+/* Same, for an arena already resident in device memory (borrowed; same contract, checked by a
+ * device-side pass).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*. */
+int  kmpgpu_attach_arena(kmpgpu_ctx *ctx, const void *d_arena, uint64_t arena_bytes,
+                         const void *d_pkt_off, const void *d_pkt_len, uint64_t n_pkts);
+
+/* Replaces the hot loop serial.c:153-155 / openmp_data.c:157-175: counts_out[i] for every
+ * pattern, in pattern order.  Synchronous; fills *t when non-NULL. */
+int  kmpgpu_scan(kmpgpu_ctx *ctx, uint64_t *counts_out, kmpgpu_timing *t);
+
+/* Asynchronous form: enqueue one full pass on the context's stream, no host synchronisation.
+ * The counts (uint64_t[n_pat]) are written to d_counts_out, a caller-owned device buffer, or to
+ * the context's own device buffer when d_counts_out is NULL.  That buffer is the operand of the
+ * cross-GPU sum that replaces MPI_Reduce(local_string_count ...), mpi_dumping.c:202. */
+int  kmpgpu_scan_enqueue(kmpgpu_ctx *ctx, void *d_counts_out);
+/* Device address of the context's own counts buffer. */
+void *kmpgpu_counts_device(kmpgpu_ctx *ctx);
+int  kmpgpu_sync(kmpgpu_ctx *ctx);
+
+/* Per-launch durations of the scan kernel, measured with HIP events on the launch stream.
+ * begin(): start recording up to max_launches launches; end(): synchronise, write the
+ * durations (ms) of the *n recorded launches, stop recording. */
+int  kmpgpu_profile_begin(kmpgpu_ctx *ctx, uint32_t max_launches);
+int  kmpgpu_profile_end(kmpgpu_ctx *ctx, float *ms_out, uint32_t *n);
+
+/* Counts plus the matches themselves, at most cap of them written to out (host memory);
+ * *n_found is the total number found (may exceed cap). */
+int  kmpgpu_scan_offsets(kmpgpu_ctx *ctx, kmpgpu_match *out, uint64_t cap, uint64_t *n_found,
+                         uint64_t *counts_out);
+
+/* Fill a device arena with the synthetic payloads of kmp_synth.h (benchmark input S1/S2):
+ * packet ids first_pkt_id .. first_pkt_id + n_pkts - 1 at the slots of the given device index. */
+int  kmpgpu_synth_fill(kmpgpu_ctx *ctx, void *d_arena, const void *d_pkt_off, const void *d_pkt_len,
+                       uint64_t first_pkt_id, uint64_t n_pkts, const kmp_synth_params *sp);
+
+/* Device-side index for n fixed-length payloads at stride round_up(len, align): writes
+ * d_pkt_off[k] = k * stride, d_pkt_len[k] = len. */
+int  kmpgpu_fixed_index(kmpgpu_ctx *ctx, void *d_pkt_off, void *d_pkt_len, uint64_t n_pkts,
+                        uint32_t len, uint32_t slot_align);
+
+/* What the arena currently attached/loaded holds. */
+int  kmpgpu_arena_info(kmpgpu_ctx *ctx, uint64_t *n_pkts, uint64_t *payload_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMPGPU_H */

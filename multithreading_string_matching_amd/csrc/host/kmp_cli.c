@@ -1,0 +1,168 @@
+/*
+ * kmp_cli.c -- the reference's command lines on top of the MI355X hot path.
+ *
+ * Built twice (csrc/Makefile):
+ *   bin/serial       ./serial <file.pcap> <string.txt> [udp/tcp]                     serial.c:2-3,33-51
+ *   bin/openmp_data  ./openmp_data <file.pcap> <string.txt> thread_number [tcp/udp]  openmp_data.c:1-2,35-54
+ * In the second form thread_number is the number of GPU shards: the payloads are split into
+ * contiguous ranges the way mpi_dumping.c:149-157 splits them over ranks (N/P each, remainder to
+ * shard 0) and the per-shard counts are summed (mpi_dumping.c:202).
+ *
+ * stdout is byte-compatible with the reference (serial.c:163-169); throughput details go to
+ * stderr.  There is no CPU fallback: without a gfx950 device the program fails with exit code 2.
+ */
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "kmpgpu.h"
+#include "kmphost.h"
+
+#ifndef KMP_CLI_OPENMP_FORM
+#define KMP_CLI_OPENMP_FORM 0
+#endif
+
+#if KMP_CLI_OPENMP_FORM
+#define PROG "./openmp_data"
+#define ARGS "<file.pcap> <string.txt> thread_number [tcp/udp]"
+#else
+#define PROG "./serial"
+#define ARGS "<file.pcap> <string.txt> [tcp/udp]"
+#endif
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static int parse_proto(const char *s, int *proto)
+{
+    if (strcmp(s, "udp") == 0) { *proto = KMP_PROTO_UDP; return 1; }       /* serial.c:38-41 */
+    if (strcmp(s, "tcp") == 0) { *proto = KMP_PROTO_TCP; return 1; }
+    return 0;
+}
+
+static void die_gpu(const char *what)
+{
+    fprintf(stderr, "%s: %s\n", what, kmpgpu_last_error());
+    exit(2);
+}
+
+int main(int argc, char *argv[])
+{
+    int proto = KMP_PROTO_UDP;                                              /* serial.c:31 */
+    int shards = 1;
+#if KMP_CLI_OPENMP_FORM
+    if (argc == 4 || argc == 5) {                                           /* openmp_data.c:35 */
+        shards = atoi(argv[3]);                                             /* openmp_data.c:38 */
+        if (argc == 5 && !parse_proto(argv[4], &proto)) {
+            printf("USAGE " PROG " " ARGS "\n");                            /* openmp_data.c:46 */
+            exit(1);
+        }
+    } else {
+        printf("USAGE: " PROG " " ARGS "\n");                               /* openmp_data.c:52 */
+        exit(1);
+    }
+    if (shards < 1) shards = 1;
+#else
+    if (argc == 3 || argc == 4) {                                           /* serial.c:33 */
+        if (argc == 4 && !parse_proto(argv[3], &proto)) {
+            printf("USAGE " PROG " " ARGS "\n");                            /* serial.c:43 */
+            exit(1);
+        }
+    } else {
+        printf("USAGE: " PROG " " ARGS "\n");                               /* serial.c:49 */
+        exit(1);
+    }
+#endif
+    const char *pcap_path = argv[1], *strings_path = argv[2];
+
+    kmp_patterns pats;
+    int rc = kmp_patterns_load(strings_path, &pats);                        /* serial.c:54-87 */
+    if (rc == KMPHOST_EIO) {
+        perror("error opening file: ");                                     /* serial.c:61 */
+        exit(1);
+    }
+    if (rc) {
+        fprintf(stderr, "error reading pattern file: %s\n", rc == KMPHOST_ETOKEN ? "token longer than 99 bytes" : "out of memory");
+        exit(1);
+    }
+
+#if !KMP_CLI_OPENMP_FORM
+    const double t_start = now_s();                                         /* serial.c:110-111: before the file read */
+#endif
+    char errbuf[KMP_PCAP_ERRBUF];
+    kmp_arena arena;
+    rc = kmp_arena_from_pcap(pcap_path, proto, kmpgpu_host_alloc, kmpgpu_host_free, &arena, errbuf);   /* serial.c:91-141 */
+    if (rc == KMPHOST_EIO || rc == KMPHOST_EFORMAT) {
+        fprintf(stderr, "error reading pcap file: %s\n", errbuf);           /* serial.c:93 */
+        exit(1);
+    }
+    if (rc) {
+        fprintf(stderr, "error building the payload arena: %s\n", errbuf[0] ? errbuf : kmpgpu_last_error());
+        exit(2);
+    }
+#if KMP_CLI_OPENMP_FORM
+    const double t_start = now_s();                                         /* openmp_data.c:126: after the pre-load */
+#endif
+
+    const int ndev = kmpgpu_device_count();
+    if (ndev <= 0) die_gpu("no MI355X device");
+
+    uint64_t *counts = (uint64_t *)calloc(pats.n ? pats.n : 1, sizeof(uint64_t));
+    uint64_t *part = (uint64_t *)calloc(pats.n ? pats.n : 1, sizeof(uint64_t));
+    const uint8_t **pp = (const uint8_t **)malloc(sizeof(uint8_t *) * (pats.n ? pats.n : 1));
+    for (uint32_t i = 0; i < pats.n; i++) pp[i] = pats.blob + pats.off[i];
+
+    double kernel_ms = 0, h2d_ms = 0;
+    if (pats.n && arena.n_pkts) {
+        if ((uint64_t)shards > arena.n_pkts) shards = (int)arena.n_pkts;
+        kmpgpu_ctx **ctx = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *ctx);
+        uint64_t *reb = (uint64_t *)malloc(sizeof(uint64_t) * arena.n_pkts);
+        uint64_t lo = 0;
+        for (int r = 0; r < shards; r++) {
+            uint64_t cnt = arena.n_pkts / (uint64_t)shards + (r == 0 ? arena.n_pkts % (uint64_t)shards : 0);   /* mpi_dumping.c:149-152 */
+            const uint64_t hi = lo + cnt;
+            const uint64_t b0 = arena.off[lo];
+            const uint64_t b1 = (hi < arena.n_pkts) ? arena.off[hi] : arena.nbytes;
+            for (uint64_t k = lo; k < hi; k++) reb[k] = arena.off[k] - b0;
+            if (kmpgpu_init(&ctx[r], r % ndev)) die_gpu("kmpgpu_init");
+            if (kmpgpu_set_patterns(ctx[r], pp, pats.len, pats.n)) die_gpu("kmpgpu_set_patterns");
+            /* slots are contiguous and at least 16 bytes each, so [b0, b1) holds the whole shard */
+            if (kmpgpu_load_arena(ctx[r], arena.bytes + b0, b1 - b0, reb + lo, arena.len + lo, cnt))
+                die_gpu("kmpgpu_load_arena");
+            lo = hi;
+        }
+        for (int r = 0; r < shards; r++) {
+            kmpgpu_timing t;
+            if (kmpgpu_scan(ctx[r], part, &t)) die_gpu("kmpgpu_scan");
+            for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];     /* mpi_dumping.c:202 MPI_SUM */
+            if (t.kernel_ms > kernel_ms) kernel_ms = t.kernel_ms;           /* mpi_dumping.c:206 MPI_MAX */
+            h2d_ms += t.h2d_ms;
+        }
+        for (int r = 0; r < shards; r++) kmpgpu_destroy(ctx[r]);
+        free(ctx); free(reb);
+    }
+    const double t_finish = now_s();                                        /* serial.c:159-160 */
+
+    kmp_report(stdout, &pats, counts, t_finish - t_start);                  /* serial.c:163-169 */
+
+    if (kernel_ms > 0) {
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < pats.n; i++) total += counts[i];
+        const double bytes = (double)arena.payload_bytes * (double)pats.n;
+        fprintf(stderr, "[kmpgpu] %llu frames, %llu payloads, %llu payload bytes, %u patterns, %d shard(s) on %d device(s)\n",
+                (unsigned long long)arena.n_frames, (unsigned long long)arena.n_pkts, (unsigned long long)arena.payload_bytes,
+                pats.n, shards, ndev);
+        fprintf(stderr, "[kmpgpu] kernel %.3f ms (%.2f GB/s payload x patterns, %.3g matches/s), h2d %.3f ms\n", kernel_ms,
+                bytes / (kernel_ms * 1e6), (double)total / (kernel_ms * 1e-3), h2d_ms);
+    }
+    free(counts); free(part); free(pp);
+    kmp_arena_free(&arena);
+    kmp_patterns_free(&pats);
+    return 0;
+}

@@ -1,0 +1,390 @@
+/*
+ * kmphost.c -- host side of the matcher (include/kmphost.h): pcap savefile reader, payload
+ * extraction, pattern loader, arena builder, report.  Plain C, no GPU dependency.  Citations are
+ * relative to the reference repository.
+ */
+#define _GNU_SOURCE
+#include "kmphost.h"
+
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ============================ pcap savefile reader =====================================
+ * What the reference obtains from libpcap: pcap_open_offline (serial.c:91), pcap_next_ex
+ * (serial.c:115).  Classic pcap: 24-byte global header {magic, ver_major, ver_minor, thiszone,
+ * sigfigs, snaplen, linktype}, then records {ts_sec, ts_frac, caplen, len} + caplen bytes. */
+struct kmp_pcap {
+    FILE    *fp;
+    int      swap;          /* file byte order differs from the host's */
+    uint32_t linktype;
+    uint32_t snaplen;
+    uint8_t *buf;
+    size_t   cap;
+};
+
+static uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+kmp_pcap *kmp_pcap_open(const char *path, char errbuf[KMP_PCAP_ERRBUF])
+{
+    if (errbuf) errbuf[0] = 0;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) {
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: %s", path, strerror(errno));
+        return NULL;
+    }
+    uint32_t h[6];
+    if (fread(h, 1, sizeof h, fp) != sizeof h) {
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "truncated dump file; tried to read %zu file header bytes", sizeof h);
+        fclose(fp);
+        return NULL;
+    }
+    int swap;
+    if (h[0] == 0xA1B2C3D4u || h[0] == 0xA1B23C4Du) swap = 0;
+    else if (bswap32(h[0]) == 0xA1B2C3D4u || bswap32(h[0]) == 0xA1B23C4Du) swap = 1;
+    else {
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "unknown file format");
+        fclose(fp);
+        return NULL;
+    }
+    kmp_pcap *p = (kmp_pcap *)calloc(1, sizeof *p);
+    if (!p) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
+    p->fp = fp;
+    p->swap = swap;
+    p->snaplen = swap ? bswap32(h[4]) : h[4];
+    p->linktype = swap ? bswap32(h[5]) : h[5];
+    return p;
+}
+
+int kmp_pcap_next(kmp_pcap *p, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+{
+    uint32_t r[4];
+    size_t got = fread(r, 1, sizeof r, p->fp);
+    if (got == 0) return -2;                    /* clean end of file */
+    if (got != sizeof r) return -1;             /* truncated record header */
+    uint32_t cl = p->swap ? bswap32(r[2]) : r[2];
+    uint32_t ln = p->swap ? bswap32(r[3]) : r[3];
+    if (cl > (64u << 20)) return -1;            /* corrupt record */
+    if (cl > p->cap) {
+        size_t nc = cl + 4096u;
+        uint8_t *nb = (uint8_t *)realloc(p->buf, nc);
+        if (!nb) return -1;
+        p->buf = nb; p->cap = nc;
+    }
+    if (cl && fread(p->buf, 1, cl, p->fp) != cl) return -1;   /* truncated packet */
+    *caplen = cl; *len = ln; *data = p->buf;
+    return 1;
+}
+
+uint32_t kmp_pcap_linktype(const kmp_pcap *p) { return p->linktype; }
+
+void kmp_pcap_close(kmp_pcap *p)
+{
+    if (!p) return;
+    if (p->fp) fclose(p->fp);
+    free(p->buf);
+    free(p);
+}
+
+/* ============================ payload extraction ======================================== */
+
+/* packet_dumping.h:87-139 */
+int kmp_extract_udp(const uint8_t *f, uint32_t cl, uint32_t *poff, uint32_t *plen)
+{
+    if (cl < 14u) return 0;                              /* :94  Ethernet header            */
+    uint32_t rest = cl - 14u;
+    if (rest < 20u) return 0;                            /* :102 minimal IP header          */
+    const uint32_t ihl = (uint32_t)(f[14] & 0x0Fu) << 2; /* :108 no version / EtherType test */
+    if (rest < ihl) return 0;                            /* :110                            */
+    if (f[14 + 9] != 17u) return 0;                      /* :116 protocol field             */
+    rest -= ihl;
+    if (rest < 8u) return 0;                             /* :125 UDP header                 */
+    *poff = 14u + ihl + 8u;                              /* :133 (sizeof(pointer) == 8)     */
+    *plen = rest - 8u;                                   /* :136 everything that was captured */
+    return 1;
+}
+
+/* packet_dumping.h:150-188; frames on which the reference's unsigned arithmetic would wrap
+ * (headers longer than the captured bytes) are rejected instead of crashing. */
+int kmp_extract_tcp(const uint8_t *f, uint32_t cl, uint32_t *poff, uint32_t *plen)
+{
+    if (cl < 15u) return 0;
+    const uint32_t size_ip = (uint32_t)(f[14] & 0x0Fu) << 2;    /* :165 */
+    if (size_ip < 20u) return 0;                                 /* :166 */
+    const uint32_t tcp_at = 14u + size_ip;
+    if (cl < tcp_at + 13u) return 0;
+    const uint32_t size_tcp = (uint32_t)(f[tcp_at + 12u] >> 4) << 2;   /* :175 */
+    if (size_tcp < 20u) return 0;                                /* :176 */
+    const uint32_t start = tcp_at + size_tcp;
+    if (cl < start) return 0;
+    *poff = start;                                               /* :181 */
+    *plen = cl - start;                                          /* :184 */
+    return 1;
+}
+
+/* ============================ pattern list ============================================== */
+
+static int is_c_space(uint8_t b) { return b == ' ' || (b >= '\t' && b <= '\r'); }
+
+/* serial.c:66 fscanf(fp, "%s", str): tokens are maximal runs of non-whitespace bytes. */
+int kmp_patterns_parse(const uint8_t *text, size_t n, kmp_patterns *out)
+{
+    memset(out, 0, sizeof *out);
+    /* pass 1: count and measure */
+    uint32_t cnt = 0;
+    size_t bytes = 0, i = 0;
+    while (i < n) {
+        while (i < n && is_c_space(text[i])) i++;
+        size_t s = i;
+        while (i < n && !is_c_space(text[i])) i++;
+        if (i > s) {
+            size_t tl = i - s;
+            const uint8_t *z = (const uint8_t *)memchr(text + s, 0, tl);   /* strlen() view, serial.c:69 */
+            if (z) tl = (size_t)(z - (text + s));
+            if (tl > KMP_MAX_PATTERN_LEN) return KMPHOST_ETOKEN;           /* would overflow char str[100] */
+            if (tl == 0) continue;
+            cnt++; bytes += tl + 1;
+        }
+    }
+    out->blob = (uint8_t *)malloc(bytes ? bytes : 1);
+    out->off = (uint32_t *)malloc(sizeof(uint32_t) * (cnt ? cnt : 1));
+    out->len = (uint32_t *)malloc(sizeof(uint32_t) * (cnt ? cnt : 1));
+    if (!out->blob || !out->off || !out->len) { kmp_patterns_free(out); return KMPHOST_ENOMEM; }
+    /* pass 2: copy */
+    uint32_t k = 0;
+    size_t w = 0;
+    i = 0;
+    while (i < n) {
+        while (i < n && is_c_space(text[i])) i++;
+        size_t s = i;
+        while (i < n && !is_c_space(text[i])) i++;
+        if (i > s) {
+            size_t tl = i - s;
+            const uint8_t *z = (const uint8_t *)memchr(text + s, 0, tl);
+            if (z) tl = (size_t)(z - (text + s));
+            if (tl == 0) continue;
+            out->off[k] = (uint32_t)w;
+            out->len[k] = (uint32_t)tl;
+            memcpy(out->blob + w, text + s, tl);
+            out->blob[w + tl] = 0;
+            w += tl + 1;
+            k++;
+        }
+    }
+    out->n = cnt;
+    return KMPHOST_OK;
+}
+
+int kmp_patterns_load(const char *path, kmp_patterns *out)
+{
+    memset(out, 0, sizeof *out);
+    FILE *fp = fopen(path, "rb");                       /* serial.c:59 */
+    if (!fp) return KMPHOST_EIO;
+    size_t cap = 1 << 16, n = 0;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    if (!buf) { fclose(fp); return KMPHOST_ENOMEM; }
+    for (;;) {
+        size_t got = fread(buf + n, 1, cap - n, fp);
+        n += got;
+        if (got == 0) break;
+        if (n == cap) {
+            uint8_t *nb = (uint8_t *)realloc(buf, cap * 2);
+            if (!nb) { free(buf); fclose(fp); return KMPHOST_ENOMEM; }
+            buf = nb; cap *= 2;
+        }
+    }
+    fclose(fp);
+    int rc = kmp_patterns_parse(buf, n, out);
+    free(buf);
+    return rc;
+}
+
+void kmp_patterns_free(kmp_patterns *p)
+{
+    if (!p) return;
+    free(p->blob); free(p->off); free(p->len);
+    memset(p, 0, sizeof *p);
+}
+
+/* serial.c:217-238 */
+void kmp_failure_table(const uint8_t *pat, uint32_t m, int32_t *prefix)
+{
+    if (!m) return;
+    prefix[0] = 0;
+    uint32_t k = 0;                                    /* length of the current border */
+    for (uint32_t q = 1; q < m; q++) {
+        while (k > 0 && pat[k] != pat[q]) k = (uint32_t)prefix[k - 1];
+        if (pat[k] == pat[q]) k++;
+        prefix[q] = (int32_t)k;
+    }
+}
+
+/* ============================ arena ===================================================== */
+
+static uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+uint64_t kmp_arena_layout(const uint32_t *lens, uint32_t fixed_len, uint64_t n, uint32_t slot_align,
+                          uint64_t *off_out, uint32_t *len_out)
+{
+    if (slot_align < KMP_SLOT_ALIGN) slot_align = KMP_SLOT_ALIGN;
+    uint64_t pos = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        const uint32_t l = lens ? lens[k] : fixed_len;
+        if (off_out) off_out[k] = pos;
+        if (len_out) len_out[k] = l;
+        pos += round_up(l ? l : 1, slot_align);         /* an empty payload still owns a slot */
+    }
+    return pos + KMP_ARENA_SLACK;
+}
+
+static int arena_alloc(kmp_arena *a, uint64_t nbytes, uint64_t n, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn)
+{
+    memset(a, 0, sizeof *a);
+    a->free_fn = alloc_fn ? free_fn : free;
+    a->bytes = (uint8_t *)(alloc_fn ? alloc_fn((size_t)nbytes) : aligned_alloc(4096, (size_t)round_up(nbytes, 4096)));
+    a->off = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+    a->len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+    if (!a->bytes || !a->off || !a->len) { kmp_arena_free(a); return KMPHOST_ENOMEM; }
+    memset(a->bytes, 0, (size_t)nbytes);
+    a->nbytes = nbytes;
+    return KMPHOST_OK;
+}
+
+void kmp_arena_free(kmp_arena *a)
+{
+    if (!a) return;
+    if (a->bytes && a->free_fn) a->free_fn(a->bytes);
+    free(a->off); free(a->len);
+    memset(a, 0, sizeof *a);
+}
+
+int kmp_arena_from_payloads(const uint8_t *const *payloads, const uint32_t *lens, uint64_t n,
+                            kmp_alloc_fn alloc_fn, kmp_free_fn free_fn, kmp_arena *out)
+{
+    const uint64_t nbytes = kmp_arena_layout(lens, 0, n, KMP_SLOT_ALIGN, NULL, NULL);
+    int rc = arena_alloc(out, nbytes, n, alloc_fn, free_fn);
+    if (rc) return rc;
+    kmp_arena_layout(lens, 0, n, KMP_SLOT_ALIGN, out->off, out->len);
+    for (uint64_t k = 0; k < n; k++) {
+        if (lens[k]) memcpy(out->bytes + out->off[k], payloads[k], lens[k]);
+        out->payload_bytes += lens[k];
+    }
+    out->n_pkts = n;
+    out->n_frames = n;
+    return KMPHOST_OK;
+}
+
+/* serial.c:115-141.  Two passes over the savefile: size the arena, then fill it, so the arena is
+ * one allocation of the final size (it may be pinned memory). */
+int kmp_arena_from_pcap(const char *path, int proto, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn,
+                        kmp_arena *out, char errbuf[KMP_PCAP_ERRBUF])
+{
+    memset(out, 0, sizeof *out);
+    uint64_t n = 0, frames = 0, bytes = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        kmp_pcap *p = kmp_pcap_open(path, errbuf);
+        if (!p) return errbuf && !strcmp(errbuf, "unknown file format") ? KMPHOST_EFORMAT : KMPHOST_EIO;
+        uint32_t cl, ln;
+        const uint8_t *data;
+        uint64_t k = 0, pos = 0;
+        while (kmp_pcap_next(p, &cl, &ln, &data) >= 0) {            /* serial.c:115 */
+            uint32_t po, pl;
+            const int ok = (proto == KMP_PROTO_TCP) ? kmp_extract_tcp(data, cl, &po, &pl)
+                                                    : kmp_extract_udp(data, cl, &po, &pl);   /* :119-122 */
+            if (pass == 0) frames++;
+            if (!ok) continue;                                      /* serial.c:138-140: skipped */
+            if (pass == 1) {
+                out->off[k] = pos;
+                out->len[k] = pl;
+                if (pl) memcpy(out->bytes + pos, data + po, pl);    /* serial.c:125-127 */
+                out->payload_bytes += pl;
+            }
+            pos += round_up(pl ? pl : 1, KMP_SLOT_ALIGN);
+            k++;
+        }
+        kmp_pcap_close(p);
+        if (pass == 0) {
+            n = k; bytes = pos + KMP_ARENA_SLACK;
+            int rc = arena_alloc(out, bytes, n, alloc_fn, free_fn);
+            if (rc) { if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return rc; }
+        }
+    }
+    out->n_pkts = n;
+    out->n_frames = frames;
+    return KMPHOST_OK;
+}
+
+/* ============================ synthetic payloads ======================================== */
+
+void kmp_synth_fill_host(uint8_t *arena, const uint64_t *off, const uint32_t *len, uint64_t first_pkt_id,
+                         uint64_t n, const kmp_synth_params *sp, int threads)
+{
+    if (threads < 1) threads = 1;
+    (void)threads;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        const uint64_t id = first_pkt_id + (uint64_t)i;
+        const uint32_t L = len[i];
+        const uint32_t key = kmp_synth_pkt_key(sp->seed, id);
+        uint32_t pos = 0;
+        const int planted = kmp_synth_plant(sp, id, L, &pos);
+        uint32_t *slot = (uint32_t *)(arena + off[i]);
+        const uint32_t nw = ((L + 15u) & ~15u) / 4u;
+        for (uint32_t w = 0; w < nw; w++) slot[w] = kmp_synth_slot_word(sp, key, w, L, planted, pos);
+    }
+}
+
+uint64_t kmp_synth_count_planted(const uint32_t *len, uint32_t fixed_len, uint64_t first_pkt_id, uint64_t n,
+                                 const kmp_synth_params *sp)
+{
+    uint64_t c = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t pos;
+        c += (uint64_t)kmp_synth_plant(sp, first_pkt_id + i, len ? len[i] : fixed_len, &pos);
+    }
+    return c;
+}
+
+/* ============================ report ==================================================== */
+
+/* serial.c:163-169 (the misspelling is the reference's). */
+void kmp_report(FILE *fp, const kmp_patterns *pats, const uint64_t *counts, double elapsed_seconds)
+{
+    fprintf(fp, "Printing the number of appereances of each string throughout the entire pcap file:\n");
+    for (uint32_t i = 0; i < pats->n; i++)
+        if (counts[i] != 0)
+            fprintf(fp, "%s: %d times!\n", (const char *)(pats->blob + pats->off[i]), (int)counts[i]);
+    fprintf(fp, "Elapsed time = %f seconds\n", elapsed_seconds);
+}
+
+/* ============================ pcap writer (tooling) ===================================== */
+
+int kmp_write_udp_pcap(const char *path, const uint8_t *arena, const uint64_t *off, const uint32_t *len, uint64_t n)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return KMPHOST_EIO;
+    const uint32_t gh[6] = {0xA1B2C3D4u, 0x00040002u, 0, 0, 262144u, 1u};   /* v2.4, Ethernet */
+    fwrite(gh, sizeof gh, 1, fp);
+    uint8_t hdr[42];
+    memset(hdr, 0, sizeof hdr);
+    for (int i = 0; i < 12; i++) hdr[i] = (uint8_t)(i + 1);
+    hdr[12] = 0x08; hdr[13] = 0x00;             /* IPv4 */
+    hdr[14] = 0x45;                             /* version 4, IHL 5 */
+    hdr[22] = 64;                               /* TTL */
+    hdr[23] = 17;                               /* UDP */
+    for (uint64_t k = 0; k < n; k++) {
+        const uint32_t L = len[k], tot = 42u + L;
+        const uint32_t rh[4] = {(uint32_t)(k / 1000000u), (uint32_t)(k % 1000000u), tot, tot};
+        hdr[16] = (uint8_t)((28u + L) >> 8); hdr[17] = (uint8_t)(28u + L);
+        hdr[38] = (uint8_t)((8u + L) >> 8); hdr[39] = (uint8_t)(8u + L);
+        if (fwrite(rh, sizeof rh, 1, fp) != 1 || fwrite(hdr, sizeof hdr, 1, fp) != 1 ||
+            (L && fwrite(arena + off[k], L, 1, fp) != 1)) {
+            fclose(fp);
+            return KMPHOST_EIO;
+        }
+    }
+    return fclose(fp) ? KMPHOST_EIO : KMPHOST_OK;
+}

@@ -1,0 +1,36 @@
+/* kmp_launch.h -- launch entry points of kmp_kernels.hip, used by the C-ABI layer (kmpgpu.hip). */
+#ifndef KMP_LAUNCH_H
+#define KMP_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmp_device.h"
+
+struct kmp_scan_args {
+    const uint8_t         *arena;
+    const uint64_t        *pkt_off;
+    const uint32_t        *pkt_len;
+    uint64_t               n_pkts;
+    const kmp_pattern_dev *patterns;     /* all patterns, file order                         */
+    const uint32_t        *pat_ids;      /* pattern index handled by blockIdx.y              */
+    uint32_t               n_ids;        /* gridDim.y                                        */
+    unsigned long long    *partials;     /* [n_ids][blocks_x]                                */
+    uint32_t               blocks_x;
+    int                    depth;        /* chunk loads in flight per wavefront              */
+    int                    mode;         /* 0 filter + confirm, 1 automaton only             */
+    bool                   masked;       /* every pattern of this launch is shorter than 4   */
+    bool                   nontemporal;
+};
+
+hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st);
+hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
+                             uint32_t n_ids, unsigned long long *counts, hipStream_t st);
+hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,
+                               uint32_t *err, unsigned long long *payload_bytes, hipStream_t st);
+hipError_t kmp_launch_synth_fill(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t first_pkt_id,
+                                 uint64_t n, const kmp_synth_params &sp, hipStream_t st);
+hipError_t kmp_launch_fixed_index(uint64_t *pkt_off, uint32_t *pkt_len, uint64_t n, uint32_t len, uint64_t stride,
+                                  hipStream_t st);
+
+#endif

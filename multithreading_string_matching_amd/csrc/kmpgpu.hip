@@ -1,0 +1,497 @@
+/*
+ * kmpgpu.hip -- C-ABI layer over the gfx950 kernels (include/kmpgpu.h).  Host code only; the
+ * kernels live in kmp_kernels.hip.  Replaces the state the reference keeps in main()'s locals
+ * (array_of_strings / prefix_array / array_of_payloads / string_count, serial.c:54,99,101,148)
+ * and the hot loop serial.c:153-155.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kmpgpu.h"
+#include "kmp_device.h"
+#include "kmp_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(KMPGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+/* Failure function, as kmp_prefix (serial.c:217-238). */
+void failure_table(const uint8_t *pat, uint32_t m, uint8_t *out)
+{
+    out[0] = 0;
+    uint32_t j = 0;
+    for (uint32_t i = 1; i < m;) {
+        if (pat[i] == pat[j]) { out[i++] = (uint8_t)++j; }
+        else if (j) { j = out[j - 1]; }
+        else { out[i++] = 0; }
+    }
+}
+
+}  // namespace
+
+struct kmpgpu_ctx {
+    int          device = 0;
+    hipStream_t  own_stream = nullptr;
+    hipStream_t  stream = nullptr;
+    int          cu_count = 256;
+
+    /* patterns */
+    uint32_t              n_pat = 0;
+    kmp_pattern_dev      *d_patterns = nullptr;
+    uint32_t             *d_ids = nullptr;          /* [n_pat]: long patterns (m >= 4) first, then short */
+    uint32_t              n_long = 0, n_short = 0;
+
+    /* arena */
+    const uint8_t  *d_arena = nullptr;
+    const uint64_t *d_off = nullptr;
+    const uint32_t *d_len = nullptr;
+    uint64_t        arena_bytes = 0, n_pkts = 0, payload_bytes = 0;
+    void           *owned_arena = nullptr, *owned_off = nullptr, *owned_len = nullptr;
+
+    /* results */
+    unsigned long long *d_partials = nullptr;
+    size_t              partials_cap = 0;             /* elements */
+    unsigned long long *d_counts = nullptr;
+    uint32_t           *d_err = nullptr;              /* [2] validation flags */
+    unsigned long long *d_sum = nullptr;
+    uint64_t           *h_counts = nullptr;           /* pinned */
+    size_t              h_counts_cap = 0;
+
+    /* options */
+    int mode = 0, blocks_per_cu = 8, depth = 4, nontemporal = 1;
+
+    /* timing */
+    hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    kmpgpu_timing last{};
+    std::vector<hipEvent_t> prof_ev;                  /* pairs */
+    uint32_t    prof_cap = 0, prof_n = 0;
+    bool        profiling = false;
+};
+
+namespace {
+
+uint32_t grid_blocks(const kmpgpu_ctx *c)
+{
+    uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
+    uint64_t cap = (uint64_t)c->cu_count * (uint64_t)c->blocks_per_cu;
+    uint64_t b = std::min(need, cap);
+    return (uint32_t)std::max<uint64_t>(b, 1);
+}
+
+int ensure_partials(kmpgpu_ctx *c, size_t elems)
+{
+    if (elems <= c->partials_cap) return KMPGPU_OK;
+    if (c->d_partials) HIP_TRY(hipFree(c->d_partials));
+    c->d_partials = nullptr; c->partials_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_partials, elems * sizeof(unsigned long long)));
+    c->partials_cap = elems;
+    return KMPGPU_OK;
+}
+
+void release_arena(kmpgpu_ctx *c)
+{
+    if (c->owned_arena) (void)hipFree(c->owned_arena);
+    if (c->owned_off) (void)hipFree(c->owned_off);
+    if (c->owned_len) (void)hipFree(c->owned_len);
+    c->owned_arena = c->owned_off = c->owned_len = nullptr;
+    c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
+    c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
+}
+
+/* Enqueue one full pass: scan launches (patterns grouped by "shorter than 4 bytes") + reduce. */
+int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
+{
+    if (!d_out) d_out = c->d_counts;
+    if (!c->d_patterns || c->n_pat == 0) return fail(KMPGPU_ESTATE, "kmpgpu_scan: no patterns set");
+    if (!c->d_off && c->n_pkts) return fail(KMPGPU_ESTATE, "kmpgpu_scan: no arena loaded");
+    uint32_t nl = 0;
+    if (c->n_pkts == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * c->n_pat, c->stream));
+        if (launches) *launches = 0;
+        return KMPGPU_OK;
+    }
+    const uint32_t bx = grid_blocks(c);
+    int rc = ensure_partials(c, (size_t)bx * c->n_pat);
+    if (rc) return rc;
+
+    kmp_scan_args a{};
+    a.arena = c->d_arena; a.pkt_off = c->d_off; a.pkt_len = c->d_len; a.n_pkts = c->n_pkts;
+    a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; a.mode = c->mode;
+    a.nontemporal = c->nontemporal != 0;
+
+    struct Group { uint32_t first, n; bool masked; } groups[2] = {{0, c->n_long, false}, {c->n_long, c->n_short, true}};
+    for (const Group &g : groups) {
+        /* gridDim.y is limited to 65535 */
+        for (uint32_t done = 0; done < g.n; done += 65535u) {
+            const uint32_t n = std::min(65535u, g.n - done);
+            a.pat_ids = c->d_ids + g.first + done;
+            a.n_ids = n;
+            a.partials = c->d_partials + (size_t)(g.first + done) * bx;
+            a.masked = g.masked;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c->profiling && c->prof_n < c->prof_cap) {
+                e0 = c->prof_ev[2 * c->prof_n]; e1 = c->prof_ev[2 * c->prof_n + 1];
+                HIP_TRY(hipEventRecord(e0, c->stream));
+            }
+            HIP_TRY(kmp_launch_scan(a, c->stream));
+            if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
+            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream));
+            ++nl;
+        }
+    }
+    if (launches) *launches = nl;
+    return KMPGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *kmpgpu_last_error(void) { return g_err.c_str(); }
+
+int kmpgpu_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(KMPGPU_EHIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return n;
+}
+
+int kmpgpu_init(kmpgpu_ctx **out, int device)
+{
+    if (!out) return fail(KMPGPU_EINVAL, "kmpgpu_init: ctx is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(KMPGPU_EHIP, "kmpgpu_init: no HIP device visible");
+    if (device < 0 || device >= n) return fail(KMPGPU_EINVAL, "kmpgpu_init: device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KMPGPU_EHIP, "kmpgpu_init: device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    kmpgpu_ctx *c = new (std::nothrow) kmpgpu_ctx();
+    if (!c) return fail(KMPGPU_ENOMEM, "kmpgpu_init: out of host memory");
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        c->stream = c->own_stream;
+        for (auto &ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    }
+    if (e == hipSuccess) e = hipMalloc(&c->d_err, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sum, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        kmpgpu_destroy(c);
+        return fail(KMPGPU_EHIP, "kmpgpu_init: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return KMPGPU_OK;
+}
+
+void kmpgpu_destroy(kmpgpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    release_arena(c);
+    if (c->d_patterns) (void)hipFree(c->d_patterns);
+    if (c->d_ids) (void)hipFree(c->d_ids);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_sum) (void)hipFree(c->d_sum);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    for (auto ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : c->prof_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int kmpgpu_set_stream(kmpgpu_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_set_stream: ctx is NULL");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_set_option: ctx is NULL");
+    switch (key) {
+    case KMPGPU_OPT_MODE:
+        if (value != 0 && value != 1) return fail(KMPGPU_EINVAL, "mode must be 0 or 1");
+        c->mode = (int)value; return KMPGPU_OK;
+    case KMPGPU_OPT_BLOCKS_PER_CU:
+        if (value < 1 || value > 64) return fail(KMPGPU_EINVAL, "blocks per CU must be 1..64");
+        c->blocks_per_cu = (int)value; return KMPGPU_OK;
+    case KMPGPU_OPT_DEPTH:
+        if (value < 2 || value > 6) return fail(KMPGPU_EINVAL, "depth must be 2..6");
+        c->depth = (int)value; return KMPGPU_OK;
+    case KMPGPU_OPT_FUSED:
+        return KMPGPU_OK;       /* reserved: fused multi-pattern pass */
+    case 100:                   /* undocumented: 0 = default cache policy loads, 1 = non-temporal */
+        c->nontemporal = value ? 1 : 0; return KMPGPU_OK;
+    default:
+        return fail(KMPGPU_EINVAL, "unknown option %d", key);
+    }
+}
+
+void *kmpgpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(KMPGPU_EHIP, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void kmpgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t *pat_len, uint32_t n_pat)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_set_patterns: ctx is NULL");
+    if (n_pat && (!pat || !pat_len)) return fail(KMPGPU_EINVAL, "kmpgpu_set_patterns: NULL pattern arrays");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<kmp_pattern_dev> host(n_pat ? n_pat : 1);
+    std::vector<uint32_t> ids_long, ids_short;
+    for (uint32_t i = 0; i < n_pat; i++) {
+        const uint32_t m = pat_len[i];
+        if (m < 1 || m > KMPGPU_MAX_PATTERN_LEN) return fail(KMPGPU_EINVAL, "pattern %u: length %u not in 1..99", i, m);
+        if (!pat[i]) return fail(KMPGPU_EINVAL, "pattern %u is NULL", i);
+        if (memchr(pat[i], 0, m)) return fail(KMPGPU_EINVAL, "pattern %u contains a 0x00 byte", i);
+        kmp_pattern_dev &d = host[i];
+        memset(&d, 0, sizeof d);
+        memcpy(d.pat, pat[i], m);
+        failure_table(d.pat, m, d.fail);
+        d.m = m;
+        const uint32_t f = m < 4 ? m : 4;
+        for (uint32_t b = 0; b < f; b++) { d.first |= (uint32_t)d.pat[b] << (8 * b); d.mask |= 0xFFu << (8 * b); }
+        (m >= 4 ? ids_long : ids_short).push_back(i);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_patterns) { HIP_TRY(hipFree(c->d_patterns)); c->d_patterns = nullptr; }
+    if (c->d_ids) { HIP_TRY(hipFree(c->d_ids)); c->d_ids = nullptr; }
+    if (c->d_counts) { HIP_TRY(hipFree(c->d_counts)); c->d_counts = nullptr; }
+    c->n_pat = n_pat; c->n_long = (uint32_t)ids_long.size(); c->n_short = (uint32_t)ids_short.size();
+    const size_t np = n_pat ? n_pat : 1;
+    HIP_TRY(hipMalloc(&c->d_patterns, np * sizeof(kmp_pattern_dev)));
+    HIP_TRY(hipMalloc(&c->d_ids, np * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->d_counts, np * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_counts, 0, np * sizeof(unsigned long long)));
+    if (n_pat) {
+        std::vector<uint32_t> ids(ids_long);
+        ids.insert(ids.end(), ids_short.begin(), ids_short.end());
+        HIP_TRY(hipMemcpy(c->d_patterns, host.data(), n_pat * sizeof(kmp_pattern_dev), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_ids, ids.data(), n_pat * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (c->h_counts_cap < np) {
+        if (c->h_counts) (void)hipHostFree(c->h_counts);
+        c->h_counts = nullptr; c->h_counts_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&c->h_counts, np * sizeof(uint64_t), hipHostMallocDefault));
+        c->h_counts_cap = np;
+    }
+    return KMPGPU_OK;
+}
+
+int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes, const uint64_t *pkt_off,
+                      const uint32_t *pkt_len, uint64_t n_pkts)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_arena: ctx is NULL");
+    if (n_pkts && (!arena || !pkt_off || !pkt_len)) return fail(KMPGPU_EINVAL, "kmpgpu_load_arena: NULL buffers");
+    uint64_t payload = 0;
+    for (uint64_t k = 0; k < n_pkts; k++) {         /* the layout contract the kernels rely on */
+        const uint64_t o = pkt_off[k], l16 = ((uint64_t)pkt_len[k] + 15u) & ~15ull;
+        if (o & 15u) return fail(KMPGPU_EINVAL, "payload %llu: offset %llu is not 16-byte aligned", (unsigned long long)k, (unsigned long long)o);
+        if (pkt_len[k] >= (1u << 30)) return fail(KMPGPU_EINVAL, "payload %llu: length %u is not below 2^30", (unsigned long long)k, pkt_len[k]);
+        if (o > arena_bytes || std::max<uint64_t>(l16, 16) > arena_bytes - o)
+            return fail(KMPGPU_EINVAL, "payload %llu: [%llu, +%llu) padded to 16 B (at least one 16-byte slot) exceeds the arena (%llu B)", (unsigned long long)k,
+                        (unsigned long long)o, (unsigned long long)pkt_len[k], (unsigned long long)arena_bytes);
+        payload += pkt_len[k];
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    release_arena(c);
+    c->last.h2d_ms = 0;
+    if (n_pkts == 0) return KMPGPU_OK;
+    if (arena_bytes < 16) return fail(KMPGPU_EINVAL, "arena smaller than 16 bytes");
+    HIP_TRY(hipMalloc(&c->owned_arena, arena_bytes));
+    HIP_TRY(hipMalloc(&c->owned_off, n_pkts * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&c->owned_len, n_pkts * sizeof(uint32_t)));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->owned_arena, arena, arena_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->owned_off, pkt_off, n_pkts * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->owned_len, pkt_len, n_pkts * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->last.h2d_ms = ms;
+    c->d_arena = (const uint8_t *)c->owned_arena;
+    c->d_off = (const uint64_t *)c->owned_off;
+    c->d_len = (const uint32_t *)c->owned_len;
+    c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = payload;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes, const void *d_pkt_off,
+                        const void *d_pkt_len, uint64_t n_pkts)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: ctx is NULL");
+    if (n_pkts && (!d_arena || !d_pkt_off || !d_pkt_len)) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: NULL buffers");
+    if (((uintptr_t)d_arena & 15u) || ((uintptr_t)d_pkt_off & 7u) || ((uintptr_t)d_pkt_len & 3u))
+        return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: misaligned device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    release_arena(c);
+    if (n_pkts == 0) return KMPGPU_OK;
+    if (arena_bytes < 16) return fail(KMPGPU_EINVAL, "arena smaller than 16 bytes");
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_sum, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(kmp_launch_validate((const uint64_t *)d_pkt_off, (const uint32_t *)d_pkt_len, n_pkts, arena_bytes, c->d_err, c->d_sum, c->stream));
+    uint32_t err[2] = {0, 0};
+    unsigned long long sum = 0;
+    HIP_TRY(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&sum, c->d_sum, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err[0] & 1u) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: a payload offset is not 16-byte aligned");
+    if (err[0] & 2u) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: a payload (padded to 16 B) exceeds the arena");
+    if (err[0] & 4u) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: a payload length is not below 2^30");
+    c->d_arena = (const uint8_t *)d_arena;
+    c->d_off = (const uint64_t *)d_pkt_off;
+    c->d_len = (const uint32_t *)d_pkt_len;
+    c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = sum;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_scan_enqueue(kmpgpu_ctx *c, void *d_counts_out)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_scan_enqueue: ctx is NULL");
+    if ((uintptr_t)d_counts_out & 7u) return fail(KMPGPU_EINVAL, "kmpgpu_scan_enqueue: d_counts_out is not 8-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    return enqueue_pass(c, nullptr, (unsigned long long *)d_counts_out);
+}
+
+void *kmpgpu_counts_device(kmpgpu_ctx *c) { return c ? (void *)c->d_counts : nullptr; }
+
+int kmpgpu_sync(kmpgpu_ctx *c)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_sync: ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return KMPGPU_OK;
+}
+
+int kmpgpu_scan(kmpgpu_ctx *c, uint64_t *counts_out, kmpgpu_timing *t)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_scan: ctx is NULL");
+    if (!counts_out && c->n_pat) return fail(KMPGPU_EINVAL, "kmpgpu_scan: counts_out is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t launches = 0;
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    int rc = enqueue_pass(c, &launches, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint64_t) * c->n_pat, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float k_ms = 0, d_ms = 0;
+    HIP_TRY(hipEventElapsedTime(&k_ms, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&d_ms, c->ev[1], c->ev[2]));
+    memcpy(counts_out, c->h_counts, sizeof(uint64_t) * c->n_pat);
+    c->last.kernel_ms = k_ms; c->last.d2h_ms = d_ms; c->last.launches = launches;
+    c->last.grid_blocks = c->n_pkts ? grid_blocks(c) : 0;
+    if (t) *t = c->last;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_profile_begin(kmpgpu_ctx *c, uint32_t max_launches)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_profile_begin: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    while (c->prof_ev.size() < 2 * (size_t)max_launches) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_cap = max_launches; c->prof_n = 0; c->profiling = true;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_profile_end(kmpgpu_ctx *c, float *ms_out, uint32_t *n)
+{
+    if (!c || !n) return fail(KMPGPU_EINVAL, "kmpgpu_profile_end: NULL argument");
+    c->profiling = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < c->prof_n; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        if (ms_out) ms_out[i] = ms;
+    }
+    *n = c->prof_n;
+    c->prof_n = 0;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_scan_offsets(kmpgpu_ctx *c, kmpgpu_match *out, uint64_t cap, uint64_t *n_found, uint64_t *counts_out)
+{
+    (void)out; (void)cap; (void)n_found; (void)counts_out;
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: ctx is NULL");
+    return fail(KMPGPU_ESTATE, "kmpgpu_scan_offsets: not built yet");
+}
+
+int kmpgpu_synth_fill(kmpgpu_ctx *c, void *d_arena, const void *d_pkt_off, const void *d_pkt_len, uint64_t first_pkt_id,
+                      uint64_t n_pkts, const kmp_synth_params *sp)
+{
+    if (!c || !sp) return fail(KMPGPU_EINVAL, "kmpgpu_synth_fill: NULL argument");
+    if (n_pkts && (!d_arena || !d_pkt_off || !d_pkt_len)) return fail(KMPGPU_EINVAL, "kmpgpu_synth_fill: NULL buffers");
+    if (sp->needle_len > KMP_SYNTH_MAX_NEEDLE || sp->span == 0 || sp->span > 256 || sp->lo + sp->span > 256)
+        return fail(KMPGPU_EINVAL, "kmpgpu_synth_fill: bad generator parameters");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(kmp_launch_synth_fill((uint8_t *)d_arena, (const uint64_t *)d_pkt_off, (const uint32_t *)d_pkt_len, first_pkt_id,
+                                  n_pkts, *sp, c->stream));
+    return KMPGPU_OK;
+}
+
+int kmpgpu_fixed_index(kmpgpu_ctx *c, void *d_pkt_off, void *d_pkt_len, uint64_t n_pkts, uint32_t len, uint32_t slot_align)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_fixed_index: ctx is NULL");
+    if (slot_align < 16 || (slot_align & (slot_align - 1))) return fail(KMPGPU_EINVAL, "slot_align must be a power of two >= 16");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t stride = ((uint64_t)len + slot_align - 1) & ~((uint64_t)slot_align - 1);
+    HIP_TRY(kmp_launch_fixed_index((uint64_t *)d_pkt_off, (uint32_t *)d_pkt_len, n_pkts, len, stride ? stride : slot_align, c->stream));
+    return KMPGPU_OK;
+}
+
+int kmpgpu_arena_info(kmpgpu_ctx *c, uint64_t *n_pkts, uint64_t *payload_bytes)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_arena_info: ctx is NULL");
+    if (n_pkts) *n_pkts = c->n_pkts;
+    if (payload_bytes) *payload_bytes = c->payload_bytes;
+    return KMPGPU_OK;
+}
+
+}  // extern "C"

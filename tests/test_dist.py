@@ -1,0 +1,87 @@
+"""The N>1 path on CPU: two gloo ranks, contiguous packet shards (mpi_dumping.c:149-157), one
+all-reduce(SUM) of the per-pattern counters (mpi_dumping.c:202), MAX of the elapsed times
+(mpi_dumping.c:206).  The local counts come from the oracle here (no GPU in this container); on
+GPUs bench.py feeds the same functions with the HIP path's counts."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import DATA, ROOT
+
+from multithreading_string_matching_amd.dist import max_over_ranks, reduce_counts, shard_range
+
+
+def test_shard_range_matches_mpi_rule():
+    for n in (0, 1, 2, 7, 8, 9, 1000, 3358):
+        for world in (1, 2, 3, 4, 8):
+            sizes = [n // world] * world
+            sizes[0] += n % world                         # mpi_dumping.c:149-152
+            lo = 0
+            for r in range(world):
+                assert shard_range(n, r, world) == (lo, lo + sizes[r])
+                lo += sizes[r]
+            assert lo == n
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, pcap, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import oracle as O
+    import multithreading_string_matching_amd as K
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = O.load()
+        pats = K.load_patterns(os.path.join(DATA, "strings.txt"))
+        a = K.HostArena.from_pcap(os.path.join(DATA, pcap), "udp")
+        lo, hi = shard_range(a.n_pkts, rank, world)
+        local, _ = o.count(a.bytes, a.off[lo:hi], a.len[lo:hi], pats)
+        t = torch.from_numpy(local.astype(np.int64))
+        reduce_counts(t)
+        mx = max_over_ranks(1.0 + rank)
+        q.put((rank, t.tolist(), mx, hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pcap,key", [("big_udp.pcap", "big_udp.pcap:udp"), ("udp.pcap", "udp.pcap:udp")])
+def test_two_rank_gloo_reduce(fixture_counts, pcap, key):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, pcap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = fixture_counts["fixtures"][key]["counts"]
+    n = fixture_counts["fixtures"][key]["payloads"]
+    assert sorted(r[3] for r in res) == sorted([n // 2 + n % 2, n // 2])
+    for rank, counts, mx, _ in res:
+        assert counts == want                             # every rank holds the global counts
+        assert mx == 2.0                                  # MAX over ranks
+
+
+def test_reduce_without_process_group_is_identity():
+    t = torch.arange(5, dtype=torch.int64)
+    assert reduce_counts(t.clone()).tolist() == t.tolist()
+    assert max_over_ranks(3.5) == 3.5
+    with pytest.raises(TypeError):
+        reduce_counts(torch.zeros(3, dtype=torch.int32))

@@ -1,0 +1,376 @@
+"""GPU parity: the HIP hot path (through the C-ABI, libkmpgpu.so) against the CPU oracle and the
+committed golden vectors.  Bit-exact: integer counts.
+
+Run on a real MI355X:  python -m pytest tests -m gpu
+"""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import DATA
+
+pytestmark = pytest.mark.gpu
+
+import multithreading_string_matching_amd as K  # noqa: E402
+from multithreading_string_matching_amd import _lib  # noqa: E402
+from multithreading_string_matching_amd.matcher import (  # noqa: E402
+    MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_MODE, OPT_NONTEMPORAL, GpuMatcher)
+
+FIXTURE_KEYS = [
+    "udp.pcap:udp", "udp_1000.pcap:udp", "big_udp.pcap:udp", "very_big_udp.pcap:udp",
+    "tcp.pcap:tcp", "tcp.pcap:udp", "udp.pcap:tcp", "udp_1000.pcap:tcp",
+]
+
+
+@pytest.fixture(scope="module")
+def gm():
+    m = GpuMatcher(0)
+    yield m
+    m.close()
+
+
+def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=4):
+    gm.set_option(OPT_MODE, mode)
+    gm.set_option(OPT_DEPTH, depth)
+    gm.set_patterns(patterns)
+    gm.load_arena(arena)
+    return gm.scan()[0]
+
+
+def check_payloads(gm, oracle, payloads, patterns, modes=(MODE_FILTER, MODE_AUTOMATON), depth=4):
+    arena = K.HostArena.from_payloads(payloads)
+    want, _ = oracle.count(arena.bytes, arena.off, arena.len, patterns)
+    for mode in modes:
+        got = gpu_counts(gm, patterns, arena, mode, depth)
+        assert got.tolist() == want.tolist(), (mode, depth, [(p, int(g), int(w)) for p, g, w in zip(patterns, got, want) if g != w][:5])
+    return want
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key", FIXTURE_KEYS)
+@pytest.mark.parametrize("mode", [MODE_FILTER, MODE_AUTOMATON])
+def test_fixture_counts(gm, fixture_counts, tokens, key, mode):
+    fx = fixture_counts["fixtures"][key]
+    arena = K.HostArena.from_pcap(os.path.join(DATA, fx["pcap"]), fx["mode"])
+    assert arena.n_pkts == fx["payloads"] and arena.payload_bytes == fx["payload_bytes"]
+    got = gpu_counts(gm, tokens, arena, mode)
+    assert got.tolist() == fx["counts"]
+
+
+def test_config1_single_pattern(gm, tokens):
+    """BASELINE configs[0]: udp_1000.pcap, first pattern of strings.txt -> 198."""
+    arena = K.HostArena.from_pcap(os.path.join(DATA, "udp_1000.pcap"), "udp")
+    assert gpu_counts(gm, [tokens[0]], arena).tolist() == [198]
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6])
+def test_depths_and_grids(gm, oracle, tokens, depth):
+    arena = K.HostArena.from_pcap(os.path.join(DATA, "big_udp.pcap"), "udp")
+    want, _ = oracle.count(arena.bytes, arena.off, arena.len, tokens)
+    for bpc in (1, 8):
+        gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+        got = gpu_counts(gm, tokens, arena, MODE_FILTER, depth)
+        assert got.tolist() == want.tolist()
+    gm.set_option(OPT_BLOCKS_PER_CU, 8)
+
+
+# ------------------------------------------------------------------------------------------------
+# known-answer vectors from the reference's own kmp_matcher
+# ------------------------------------------------------------------------------------------------
+def test_kat_vectors(gm, oracle, kat_matcher):
+    by_pat = {}
+    for k in kat_matcher:
+        by_pat.setdefault(bytes.fromhex(k["pat"]), []).append((bytes.fromhex(k["text"]), k["count"]))
+    pats = sorted(by_pat)
+    texts = sorted({t for v in by_pat.values() for t, _ in v})
+    arena = K.HostArena.from_payloads(texts)
+    for mode in (MODE_FILTER, MODE_AUTOMATON):
+        got = gpu_counts(gm, pats, arena, mode)
+        want, _ = oracle.count(arena.bytes, arena.off, arena.len, pats)
+        assert got.tolist() == want.tolist()
+    # and each vector on its own (one payload, one pattern): the reference's exact answers
+    for pat, cases in by_pat.items():
+        arena = K.HostArena.from_payloads([t for t, _ in cases])
+        got = gpu_counts(gm, [pat], arena)
+        assert int(got[0]) == sum(c for _, c in cases), pat
+
+
+# ------------------------------------------------------------------------------------------------
+# crafted edge cases
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8, 15, 16, 17, 33, 64, 99])
+def test_match_at_every_offset(gm, oracle, m):
+    """One planted match per payload, at every start offset 0..2200: lane, chunk and slot straddling."""
+    pat = bytes((0x41 + (i * 7) % 26) for i in range(m))
+    L = 2300
+    payloads = []
+    for s in range(0, L - m + 1):
+        b = bytearray(b"z" * L)
+        b[s:s + m] = pat
+        payloads.append(bytes(b))
+    want = check_payloads(gm, oracle, payloads, [pat])
+    assert int(want[0]) == len(payloads)
+
+
+def test_match_ends_on_last_byte_all_lengths(gm, oracle):
+    pats = [b"Q", b"QR", b"QRS", b"QRST", b"QRSTU", b"QRSTUVWXYZ012345"]
+    payloads = []
+    for L in list(range(0, 70)) + [1007, 1008, 1009, 1023, 1024, 1025, 1039, 1040, 1041, 2047, 2048, 2049, 3072]:
+        for p in pats:
+            if L >= len(p):
+                payloads.append(b"." * (L - len(p)) + p)
+    check_payloads(gm, oracle, payloads, pats)
+
+
+def test_overlapping(gm, oracle):
+    payloads = [b"a" * n for n in (0, 1, 2, 3, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 1500, 4097)]
+    payloads += [b"ab" * 700, b"aab" * 500, b"abcab" * 321]
+    pats = [b"a", b"aa", b"aaa", b"aaaa", b"aaaaa", b"a" * 16, b"a" * 17, b"a" * 99, b"abab", b"ababab", b"aabaab", b"abcabcab", b"ab" * 20]
+    want = check_payloads(gm, oracle, payloads, pats)
+    assert int(want[1]) == sum(max(0, len(p) - 1) for p in payloads[:15])       # 'aa' in 'a'*n -> n-1
+
+
+def test_nul_rule(gm, oracle):
+    pats = [b"http", b"ht", b"h", b"http-long-pattern"]
+    base = b"http-long-pattern http xx http" * 40          # 1200 bytes
+    payloads = [base]
+    for z in list(range(0, 40)) + [100, 500, 1007, 1008, 1023, 1024, 1025, 1100, 1199]:
+        b = bytearray(base)
+        b[z] = 0
+        payloads.append(bytes(b))
+    payloads += [b"\0" + base, base + b"\0", b"\0" * 50, b"http\0http", b"ht\0tp", base * 3 + b"\0" + base]
+    two = bytearray(base * 2)
+    two[1500] = 0
+    two[30] = 0
+    payloads.append(bytes(two))
+    check_payloads(gm, oracle, payloads, pats)
+
+
+def test_high_bit_bytes_and_all_values(gm, oracle):
+    rng = random.Random(5)
+    pats = [bytes([0x80, 0xFF]), bytes([0xFF]), bytes([0xFE, 0xFF, 0x80, 0x81, 0xC3]), bytes([1, 2, 3, 4]), bytes(range(200, 216))]
+    payloads = []
+    for _ in range(200):
+        n = rng.randrange(0, 2500)
+        b = bytearray(rng.randrange(1, 256) for _ in range(n))
+        for _ in range(rng.randrange(0, 6)):
+            p = rng.choice(pats)
+            if n > len(p):
+                s = rng.randrange(0, n - len(p))
+                b[s:s + len(p)] = p
+        if rng.random() < 0.3 and n:
+            b[rng.randrange(n)] = 0
+        payloads.append(bytes(b))
+    check_payloads(gm, oracle, payloads, pats)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_small_alphabet(gm, oracle, seed):
+    """Dense candidates: low-entropy text, many overlapping hits, NULs, ragged lengths."""
+    rng = np.random.default_rng(seed)
+    n = 3000
+    lens = rng.integers(0, 2600, size=n)
+    lens[:50] = 0
+    lens[50:100] = rng.integers(1, 20, size=50)
+    payloads = []
+    for L in lens:
+        a = rng.integers(1, 4, size=int(L), dtype=np.uint8) + 96          # 'a','b','c'
+        if L and rng.random() < 0.4:
+            a[rng.integers(0, L)] = 0
+        payloads.append(a.tobytes())
+    pats = [b"a", b"ab", b"abc", b"abca", b"abcab", b"aaaaaa", b"abcabcabc", b"cbacbacbacbacbacb", b"ab" * 17]
+    check_payloads(gm, oracle, payloads, pats)
+
+
+def test_long_payloads(gm, oracle):
+    rng = np.random.default_rng(9)
+    payloads = []
+    for L in (9000, 65535, 200_000):
+        a = rng.integers(97, 123, size=L, dtype=np.uint8)
+        for s in range(7, L - 40, 997):
+            a[s:s + 16] = np.frombuffer(b"NEEDLE_16B_PATRN", dtype=np.uint8)
+        payloads.append(a.tobytes())
+    z = bytearray(payloads[1])
+    z[40000] = 0
+    payloads.append(bytes(z))
+    check_payloads(gm, oracle, payloads, [b"NEEDLE_16B_PATRN", b"NE", b"N", b"zz"])
+
+
+def test_empty_inputs(gm, oracle):
+    arena = K.HostArena.from_payloads([])
+    assert gpu_counts(gm, [b"http"], arena).tolist() == [0]
+    check_payloads(gm, oracle, [b"", b"", b""], [b"x", b"http"])
+    check_payloads(gm, oracle, [b"x"], [b"x", b"xx"])
+
+
+def test_layout_contract_is_checked(gm):
+    gm.set_patterns([b"http"])
+    a = np.zeros(256, dtype=np.uint8)
+    with pytest.raises(K.KmpGpuError):
+        gm.load_arena(a, np.array([8], dtype=np.uint64), np.array([10], dtype=np.uint32))      # misaligned
+    with pytest.raises(K.KmpGpuError):
+        gm.load_arena(a, np.array([240], dtype=np.uint64), np.array([20], dtype=np.uint32))    # out of bounds
+    with pytest.raises(K.KmpGpuError):
+        gm.set_patterns([b"a\0b"])
+    with pytest.raises(K.KmpGpuError):
+        gm.set_patterns([b"x" * 100])
+    gm.set_patterns([b"http"])
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic benchmark input
+# ------------------------------------------------------------------------------------------------
+def _device_synth(gm, n, length, sp, lens=None):
+    import torch
+    if lens is None:
+        off, ln, nbytes = K.arena_layout(None, length, n)
+    else:
+        off, ln, nbytes = K.arena_layout(lens, 0, n)
+    d_arena = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(ln.astype(np.int32)).cuda()
+    gm.set_stream(torch.cuda.current_stream().cuda_stream)
+    gm.synth_fill(d_arena, d_off, d_len, sp)
+    torch.cuda.synchronize()
+    return d_arena, d_off, d_len, off, ln, nbytes
+
+
+def test_synth_device_equals_host_and_oracle(gm, oracle):
+    import torch
+    needle = b"NEEDLE_16B_PATRN"
+    sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
+    n = 20000
+    d_arena, d_off, d_len, off, ln, nbytes = _device_synth(gm, n, 1500, sp)
+    host = np.zeros(nbytes, dtype=np.uint8)
+    K.synth_fill_host(host, off, ln, sp, threads=4)
+    dev = d_arena.cpu().numpy()
+    assert np.array_equal(dev, host)
+    gm.set_patterns([needle, b"qz", b"a"])
+    gm.attach_arena(d_arena, d_off, d_len)
+    got, _ = gm.scan()
+    want, _ = oracle.count(host, off, ln, [needle, b"qz", b"a"], threads=8)
+    assert got.tolist() == want.tolist()
+    assert int(got[0]) == K.synth_count_planted(sp, n, 1500)
+    gm.set_stream(None)
+    del d_arena, d_off, d_len
+    torch.cuda.empty_cache()
+
+
+def test_synth_zipf_with_nuls(gm, oracle):
+    """BASELINE configs[4] shape: lengths 64..9000, Zipf; NUL sprinkling exercises the strlen rule."""
+    import torch
+    rng = np.random.default_rng(4)
+    ranks = np.arange(1, 9000 - 64 + 2)
+    p = 1.0 / ranks ** 1.1
+    p /= p.sum()
+    lens = (64 + rng.choice(len(ranks), size=6000, p=p)).astype(np.uint32)
+    lens[:5] = [9000, 8999, 64, 1024, 2048]
+    needle = b"NEEDLE_16B_PATRN"
+    for nul_ppm in (0, 1000):
+        sp = K.SynthParams.make(seed=77, needle=needle, plant_permille=300, nul_ppm=nul_ppm)
+        d_arena, d_off, d_len, off, ln, nbytes = _device_synth(gm, len(lens), 0, sp, lens)
+        host = d_arena.cpu().numpy()
+        pats = [needle, b"ab", b"NEEDLE"]
+        gm.set_patterns(pats)
+        gm.attach_arena(d_arena, d_off, d_len)
+        want, _ = oracle.count(host, off, ln, pats, threads=8)
+        for mode in (MODE_FILTER, MODE_AUTOMATON):
+            gm.set_option(OPT_MODE, mode)
+            got, _ = gm.scan()
+            assert got.tolist() == want.tolist()
+        gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_stream(None)
+
+
+def test_full_size_property_1m(gm):
+    """BASELINE configs[1] at full size: 1 M x 1500 B, one 16-byte pattern.  Size-independent
+    checks: count == number of planted packets (closed form from the generator), identical for
+    both kernels' cache policies and grid shapes, and additive under sharding."""
+    import torch
+    needle = b"NEEDLE_16B_PATRN"
+    sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
+    n = 1_000_000
+    d_arena, d_off, d_len, off, ln, nbytes = _device_synth(gm, n, 1500, sp)
+    planted = K.synth_count_planted(sp, n, 1500)
+    gm.set_patterns([needle])
+    gm.attach_arena(d_arena, d_off, d_len)
+    assert gm.arena_info() == (n, n * 1500)
+    for nt in (1, 0):
+        for bpc in (8, 3):
+            gm.set_option(OPT_NONTEMPORAL, nt)
+            gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+            got, t = gm.scan()
+            assert int(got[0]) == planted
+    gm.set_option(OPT_NONTEMPORAL, 1)
+    gm.set_option(OPT_BLOCKS_PER_CU, 8)
+    # sharding: three uneven contiguous ranges must add up (mpi_dumping.c:149-157 property)
+    total = 0
+    for lo, hi in ((0, 333_334), (333_334, 666_667), (666_667, n)):
+        b0 = int(off[lo])
+        sub_off = torch.from_numpy((off[lo:hi] - off[lo]).astype(np.int64)).cuda()
+        gm.attach_arena(d_arena[b0:], sub_off, d_len[lo:hi])
+        total += int(gm.scan()[0][0])
+    assert total == planted
+    gm.set_stream(None)
+
+
+# ------------------------------------------------------------------------------------------------
+# the drop-in command lines
+# ------------------------------------------------------------------------------------------------
+def _run(prog, *args):
+    exe = os.path.join(_lib.BINDIR, prog)
+    return subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
+
+
+def _strip_elapsed(out):
+    lines = out.splitlines(keepends=True)
+    assert lines and lines[-1].startswith("Elapsed time = ") and lines[-1].endswith(" seconds\n")
+    return "".join(lines[:-1])
+
+
+@pytest.mark.parametrize("key", FIXTURE_KEYS)
+def test_cli_serial_stdout(fixture_counts, tokens, key):
+    fx = fixture_counts["fixtures"][key]
+    r = _run("serial", os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt"), fx["mode"])
+    assert r.returncode == 0, r.stderr
+    assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
+def test_cli_default_protocol_is_udp(fixture_counts, tokens):
+    fx = fixture_counts["fixtures"]["udp_1000.pcap:udp"]
+    r = _run("serial", os.path.join(DATA, "udp_1000.pcap"), os.path.join(DATA, "strings.txt"))
+    assert r.returncode == 0 and _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
+@pytest.mark.parametrize("shards", ["1", "2", "3", "8"])
+def test_cli_openmp_data_form(fixture_counts, tokens, shards):
+    fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
+    r = _run("openmp_data", os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), shards, "udp")
+    assert r.returncode == 0, r.stderr
+    assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+    r = _run("openmp_data", os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), shards)
+    assert r.returncode == 0 and _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
+def test_cli_pcap_route_equals_arena_route(gm, tmp_path):
+    """A synthetic arena written out as a pcap and read back through bin/serial gives the count
+    the arena route gives (arena-route == pcap-route)."""
+    needle = b"NEEDLE_16B_PATRN"
+    sp = K.SynthParams.make(seed=99, needle=needle, plant_permille=200)
+    n = 5000
+    off, ln, nbytes = K.arena_layout(None, 1500, n)
+    host = np.zeros(nbytes, dtype=np.uint8)
+    K.synth_fill_host(host, off, ln, sp)
+    pcap = str(tmp_path / "synth.pcap")
+    K.write_udp_pcap(pcap, host, off, ln)
+    strings = tmp_path / "needle.txt"
+    strings.write_text(needle.decode() + "\n")
+    r = _run("serial", pcap, str(strings), "udp")
+    assert r.returncode == 0, r.stderr
+    planted = K.synth_count_planted(sp, n, 1500)
+    assert _strip_elapsed(r.stdout) == K.format_report([needle], [planted])
