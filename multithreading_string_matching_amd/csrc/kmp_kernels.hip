@@ -329,6 +329,204 @@ kmp_scan_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ 
     }
 }
 
+/* ================================================================================================
+ * Uniform-stride arenas (every payload the same length, slots back to back): flat streaming.
+ *
+ * Each wavefront owns a CONTIGUOUS run of packets, i.e. one contiguous byte range of the arena,
+ * and streams it in 1 KiB chunks irrespective of packet boundaries: every lane always holds 16
+ * useful bytes, consecutive chunk loads are consecutive addresses, and there is no per-packet
+ * scalar work at all.  Because slots are 16-byte aligned a lane's 16 bytes belong to exactly one
+ * packet; the lane tracks p0 = offset of its first byte inside that packet's slot with one
+ * add + min per chunk.  Still one packet per wavefront at a time: the packets of a range are
+ * scanned in order by the same wavefront, so the "first 0x00 ends the text" rule (serial.c:191)
+ * is wave-local state (dead: the packet entering the chunk already had a NUL).
+ *
+ * A start offset s (lane position i, s = p0 + i) counts iff
+ *     s + m <= L                       window inside the payload                  (serial.c:193,198)
+ *     no 0x00 in the packet before s   strlen() stopped earlier otherwise         (serial.c:191)
+ *     text[s : s+m] == pattern         (a NUL inside the window fails here: patterns are NUL-free)
+ * ============================================================================================== */
+
+/* Candidate test for the 16 start offsets of a lane, VALU only: min over (dword ^ first). */
+template <bool MASKED>
+__device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t first, uint32_t mask)
+{
+    uint32_t acc = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t lo = w[q], hi = w[q + 1];
+        uint32_t x0 = lo ^ first;
+        uint32_t x1 = __builtin_amdgcn_alignbyte(hi, lo, 1) ^ first;
+        uint32_t x2 = __builtin_amdgcn_alignbyte(hi, lo, 2) ^ first;
+        uint32_t x3 = __builtin_amdgcn_alignbyte(hi, lo, 3) ^ first;
+        if (MASKED) { x0 &= mask; x1 &= mask; x2 &= mask; x3 &= mask; }
+        acc = min(acc, min(x0, x1));
+        acc = min(acc, min(x2, x3));
+    }
+    return acc;                 /* 0 iff some start offset of this lane shows the pattern's first bytes */
+}
+
+template <bool NT>
+__device__ __forceinline__ void flat_issue(u32x4 &dst, const uint8_t *__restrict__ base, uint32_t vo)
+{
+    if (NT)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+    else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+}
+
+/* KMP automaton for the flat kernel: lane scans the text from its own first byte; it stops at a
+ * 0x00 (serial.c:191) or at the payload end; matches found all start inside the lane's 16 bytes
+ * because at most 15 + m bytes are consumed. */
+__device__ __forceinline__ void automaton_flat(uint4 cur, uint4 nxt, bool act, uint32_t p0, uint32_t L, uint32_t m,
+                                               const kmp_pattern_dev &sp, uint32_t &cnt)
+{
+    uint32_t j = 0u;
+    const uint32_t nsteps = 15u + m;
+    uint32_t c0 = cur.x, c1 = cur.y, c2 = cur.z, c3 = cur.w;
+    uint32_t n0 = nxt.x, n1 = nxt.y, n2 = nxt.z, n3 = nxt.w;
+    uint32_t t0 = p0;
+    for (uint32_t done = 0u; done < nsteps; done += 16u) {
+        const uint32_t lim = min(16u, nsteps - done);
+#pragma unroll 1
+        for (uint32_t s = 0u; s < lim; ++s) {
+            const uint32_t w  = (s & 8u) ? ((s & 4u) ? c3 : c2) : ((s & 4u) ? c1 : c0);
+            const uint32_t ch = (w >> (8u * (s & 3u))) & 0xFFu;
+            act = act && (ch != 0u) && (t0 + s < L);
+            if (act) kmp_step(ch, j, m, sp.pat, sp.fail, cnt);
+        }
+        t0 += 16u;
+        if (__ballot(act) == 0ull) break;
+        const uint32_t f0 = sgpr(n0), f1 = sgpr(n1), f2 = sgpr(n2), f3 = sgpr(n3);
+        c0 = wave_shl1(c0, f0); c1 = wave_shl1(c1, f1); c2 = wave_shl1(c2, f2); c3 = wave_shl1(c3, f3);
+        n0 = wave_shl1(n0, 0u); n1 = wave_shl1(n1, 0u); n2 = wave_shl1(n2, 0u); n3 = wave_shl1(n3, 0u);
+    }
+}
+
+template <int DEPTH, bool MASKED, bool NT>
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
+                     uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
+                     const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials)
+{
+    __shared__ kmp_pattern_dev s_pat;
+    __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
+
+    const uint32_t pid = pat_ids[blockIdx.y];
+    const kmp_pattern_dev *gp = patterns + pid;
+    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
+        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t m = gp->m, first = gp->first, mask = gp->mask;
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint32_t wave = sgpr(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+
+    /* this wavefront's packets [k0, k1) = bytes [0, range) behind base */
+    const uint64_t k0 = gw * pkts_per_wave;
+    const uint64_t k1 = min(n_pkts, k0 + pkts_per_wave);
+    const uint32_t range = (k0 < n_pkts) ? (uint32_t)(k1 - k0) * stride : 0u;      /* host guarantees < 2^31 */
+    const uint8_t *base = arena + ((k0 < n_pkts) ? k0 * (uint64_t)stride : 0ull);
+    const uint32_t nchunks = (range + KMP_CHUNK - 1u) / KMP_CHUNK;
+    const uint32_t last_vo = range ? range - KMP_LANE_BYTES : 0u;                    /* clamp target of the tail chunk */
+    const uint32_t step_mod = KMP_CHUNK % stride;                                    /* p0 advance per chunk (mod stride) */
+
+    uint32_t cnt = 0u;
+    if (nchunks) {
+        const uint32_t vo0 = lane * KMP_LANE_BYTES;
+        u32x4 buf[DEPTH];
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], base, min(vo0 + (uint32_t)s * KMP_CHUNK, last_vo));
+
+        uint32_t p0 = vo0 % stride;          /* offset of this lane's first byte inside its packet's slot */
+        bool     dead = false;               /* the packet that enters the chunk already had a 0x00      */
+        uint32_t cb = 0u;                    /* byte offset of the chunk being consumed                   */
+        uint32_t j = 0u;                     /* its index                                                 */
+
+        while (j < nchunks) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (j < nchunks) {
+                    const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    const u32x4    bn  = buf[(s + 1) % DEPTH];
+                    const bool     has_next = (j + 1u < nchunks);
+                    const uint4    vn  = has_next ? make_uint4(bn.x, bn.y, bn.z, bn.w) : make_uint4(0u, 0u, 0u, 0u);
+                    const bool     inr = (cb + vo0) < range;                  /* lane holds bytes of the range */
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(vn.x))};
+
+                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
+                    const uint32_t fm = filter_min<MASKED>(w, first, mask);
+                    const uint64_t zl = __ballot(inr && zm != 0u);            /* lanes holding a 0x00           */
+                    const uint64_t st = __ballot(inr && p0 == 0u);            /* lanes where a packet starts    */
+                    const uint64_t cl = __ballot(inr && fm == 0u);            /* lanes with a candidate         */
+                    const bool dead_in = dead;
+                    /* carry for the next chunk: zeros at or after the last packet start of this chunk */
+                    if (st == 0ull) dead = dead || (zl != 0ull);
+                    else            dead = (zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull;
+
+                    if (cl != 0ull) {
+                        /* rare path.  Has the packet of this lane a 0x00 before the lane's bytes? */
+                        const uint64_t below = (1ull << lane) - 1ull;
+                        const uint64_t st_le = st & (below | (1ull << lane));
+                        bool nul_before;
+                        if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
+                        else {
+                            const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
+                            nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
+                        }
+                        /* index of the first 0x00 inside the lane's own 16 bytes (16 = none) */
+                        const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
+                        uint32_t zi = 16u;
+                        if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
+                        if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
+                        if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
+                        if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
+                        const bool lane_ok = inr && (fm == 0u) && !nul_before;
+                        if (m <= 4u) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const uint32_t lo = w[q], hi = w[q + 1];
+#pragma unroll
+                                for (int a = 0; a < 4; ++a) {
+                                    const uint32_t i = (uint32_t)(4 * q + a);
+                                    const uint32_t d = a ? __builtin_amdgcn_alignbyte(hi, lo, a) : lo;
+                                    if (lane_ok && is_cand<MASKED>(d, first, mask) && (i < zi) && (p0 + i + m <= L)) ++cnt;
+                                }
+                            }
+                        } else {
+                            const bool act = lane_ok && (p0 + m <= L);
+                            if (__ballot(act) != 0ull) automaton_flat(v, vn, act, p0, L, m, s_pat, cnt);
+                        }
+                    }
+                    /* advance to the next chunk */
+                    p0 += step_mod;
+                    p0 = min(p0, p0 - stride);               /* unsigned: subtracts stride iff p0 >= stride */
+                    cb += KMP_CHUNK;
+                    ++j;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                flat_issue<NT>(buf[s], base, min(vo0 + cb + (uint32_t)(DEPTH - 1) * KMP_CHUNK, last_vo));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+    }
+
+    unsigned long long c64 = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+    if (lane == 0u) s_wave_cnt[wave] = c64;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) t += s_wave_cnt[i];
+        partials[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 /* counts[pat_ids[y]] = sum of that pattern's block partials. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t blocks_x,
@@ -350,14 +548,20 @@ kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t bloc
 }
 
 /* Layout contract of kmpgpu.h for a device-resident index: err[0] |= 1 misaligned, |= 2 out of
- * bounds; payload_bytes += sum(len). */
+ * bounds, |= 4 length >= 2^30; err[1] != 0: the arena is NOT uniform-stride; info[0] += sum(len),
+ * info[1..3] = offset of payload 0, stride (offset 1 - offset 0), length of payload 0. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len, uint64_t n,
-                          uint64_t arena_bytes, uint32_t *__restrict__ err, unsigned long long *__restrict__ payload_bytes)
+                          uint64_t arena_bytes, uint32_t *__restrict__ err, unsigned long long *__restrict__ info)
 {
     __shared__ unsigned long long s[KMP_BLOCK_WAVES];
     unsigned long long sum = 0ull;
-    uint32_t e = 0u;
+    uint32_t e = 0u, nonuni = 0u;
+    const uint64_t off0 = pkt_off[0];
+    const uint32_t len0 = pkt_len[0];
+    const uint64_t l016 = ((uint64_t)len0 + 15ull) & ~15ull;
+    const uint64_t stride = (n > 1) ? pkt_off[1] - off0 : (l016 < 16ull ? 16ull : l016);
+    if ((n > 1 && pkt_off[1] < off0) || stride < (l016 < 16ull ? 16ull : l016) || (stride & 15ull)) nonuni = 1u;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t o = pkt_off[k];
         const uint64_t l = pkt_len[k];
@@ -365,9 +569,11 @@ kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *
         if (l >= (1ull << 30)) e |= 4u;
         const uint64_t l16 = (l + 15ull) & ~15ull;
         if (o > arena_bytes || (l16 < 16ull ? 16ull : l16) > arena_bytes - o) e |= 2u;   /* every payload owns >= 16 readable bytes */
+        if (l != len0 || o != off0 + k * stride) nonuni = 1u;
         sum += l;
     }
     if (e) atomicOr(err, e);
+    if (nonuni) atomicOr(err + 1, 1u);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((threadIdx.x & 63u) == 0u) s[threadIdx.x >> 6] = sum;
@@ -375,7 +581,8 @@ kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *
     if (threadIdx.x == 0u) {
         unsigned long long r = 0ull;
         for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) r += s[i];
-        atomicAdd(payload_bytes, r);
+        atomicAdd(info, r);
+        if (blockIdx.x == 0u) { info[1] = off0; info[2] = stride; info[3] = len0; }
     }
 }
 
@@ -441,6 +648,40 @@ hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st)
     if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
     if (a.mode == 1) return launch_scan_d<true, 1>(a, st);      /* MASKED is unused by the automaton */
     return a.masked ? launch_scan_d<true, 0>(a, st) : launch_scan_d<false, 0>(a, st);
+}
+
+namespace {
+template <int DEPTH, bool MASKED>
+hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
+{
+    dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
+    if (a.nontemporal)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
+                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+    else
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, false>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
+                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+    return hipGetLastError();
+}
+template <bool MASKED>
+hipError_t launch_flat_d(const kmp_scan_args &a, hipStream_t st)
+{
+    switch (a.depth) {
+    case 2: return launch_flat_t<2, MASKED>(a, st);
+    case 3: return launch_flat_t<3, MASKED>(a, st);
+    case 5: return launch_flat_t<5, MASKED>(a, st);
+    case 6: return launch_flat_t<6, MASKED>(a, st);
+    case 8: return launch_flat_t<8, MASKED>(a, st);
+    default: return launch_flat_t<4, MASKED>(a, st);
+    }
+}
+}  // namespace
+
+/* Flat streaming kernel for uniform-stride arenas (a.arena already points at payload 0). */
+hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st)
+{
+    if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
+    return a.masked ? launch_flat_d<true>(a, st) : launch_flat_d<false>(a, st);
 }
 
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,

@@ -21,9 +21,14 @@ struct kmp_scan_args {
     int                    mode;         /* 0 filter + confirm, 1 automaton only             */
     bool                   masked;       /* every pattern of this launch is shorter than 4   */
     bool                   nontemporal;
+    /* flat kernel only: every payload has length uniform_len, payload k starts at arena + k * uniform_stride */
+    uint32_t               uniform_stride;
+    uint32_t               uniform_len;
+    uint32_t               pkts_per_wave;
 };
 
 hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st);
+hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,

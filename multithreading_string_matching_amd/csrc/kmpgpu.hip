@@ -69,6 +69,9 @@ struct kmpgpu_ctx {
     const uint64_t *d_off = nullptr;
     const uint32_t *d_len = nullptr;
     uint64_t        arena_bytes = 0, n_pkts = 0, payload_bytes = 0;
+    bool            uniform = false;                  /* every payload has the same length, slots back to back */
+    uint64_t        uni_off0 = 0;
+    uint32_t        uni_stride = 0, uni_len = 0;
     void           *owned_arena = nullptr, *owned_off = nullptr, *owned_len = nullptr;
 
     /* results */
@@ -76,12 +79,12 @@ struct kmpgpu_ctx {
     size_t              partials_cap = 0;             /* elements */
     unsigned long long *d_counts = nullptr;
     uint32_t           *d_err = nullptr;              /* [2] validation flags */
-    unsigned long long *d_sum = nullptr;
+    unsigned long long *d_sum = nullptr;              /* [4] payload bytes, offset 0, stride, length 0 */
     uint64_t           *h_counts = nullptr;           /* pinned */
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 8, depth = 4, nontemporal = 1;
+    int mode = 0, blocks_per_cu = 8, depth = 4, nontemporal = 1, kernel_sel = 0;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -119,6 +122,7 @@ void release_arena(kmpgpu_ctx *c)
     c->owned_arena = c->owned_off = c->owned_len = nullptr;
     c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
     c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
+    c->uniform = false;
 }
 
 /* Enqueue one full pass: scan launches (patterns grouped by "shorter than 4 bytes") + reduce. */
@@ -141,6 +145,14 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
     a.arena = c->d_arena; a.pkt_off = c->d_off; a.pkt_len = c->d_len; a.n_pkts = c->n_pkts;
     a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; a.mode = c->mode;
     a.nontemporal = c->nontemporal != 0;
+    /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
+    const uint64_t nwaves = (uint64_t)bx * KMP_BLOCK_WAVES;
+    const uint64_t ppw = (c->n_pkts + nwaves - 1) / nwaves;
+    const bool flat = c->uniform && c->kernel_sel == 0 && c->mode == 0 && ppw * c->uni_stride < (1ull << 31);
+    if (flat) {
+        a.arena = c->d_arena + c->uni_off0;
+        a.uniform_stride = c->uni_stride; a.uniform_len = c->uni_len; a.pkts_per_wave = (uint32_t)ppw;
+    }
 
     struct Group { uint32_t first, n; bool masked; } groups[2] = {{0, c->n_long, false}, {c->n_long, c->n_short, true}};
     for (const Group &g : groups) {
@@ -156,7 +168,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
                 e0 = c->prof_ev[2 * c->prof_n]; e1 = c->prof_ev[2 * c->prof_n + 1];
                 HIP_TRY(hipEventRecord(e0, c->stream));
             }
-            HIP_TRY(kmp_launch_scan(a, c->stream));
+            HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream));
             ++nl;
@@ -203,7 +215,7 @@ int kmpgpu_init(kmpgpu_ctx **out, int device)
         for (auto &ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     }
     if (e == hipSuccess) e = hipMalloc(&c->d_err, 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_sum, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sum, 4 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         kmpgpu_destroy(c);
         return fail(KMPGPU_EHIP, "kmpgpu_init: %s", hipGetErrorString(e));
@@ -249,10 +261,13 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
         if (value < 1 || value > 64) return fail(KMPGPU_EINVAL, "blocks per CU must be 1..64");
         c->blocks_per_cu = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_DEPTH:
-        if (value < 2 || value > 6) return fail(KMPGPU_EINVAL, "depth must be 2..6");
+        if (value < 2 || value > 8 || value == 7) return fail(KMPGPU_EINVAL, "depth must be 2..6 or 8");
         c->depth = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_FUSED:
         return KMPGPU_OK;       /* reserved: fused multi-pattern pass */
+    case KMPGPU_OPT_KERNEL:
+        if (value != 0 && value != 1) return fail(KMPGPU_EINVAL, "kernel selection must be 0 or 1");
+        c->kernel_sel = (int)value; return KMPGPU_OK;
     case 100:                   /* undocumented: 0 = default cache policy loads, 1 = non-temporal */
         c->nontemporal = value ? 1 : 0; return KMPGPU_OK;
     default:
@@ -333,6 +348,16 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
                         (unsigned long long)o, (unsigned long long)pkt_len[k], (unsigned long long)arena_bytes);
         payload += pkt_len[k];
     }
+    bool uniform = n_pkts > 0;
+    uint64_t ustride = 0;
+    if (uniform) {
+        const uint64_t l16 = std::max<uint64_t>(((uint64_t)pkt_len[0] + 15u) & ~15ull, 16);
+        ustride = n_pkts > 1 ? pkt_off[1] - pkt_off[0] : l16;
+        if (n_pkts > 1 && pkt_off[1] < pkt_off[0]) uniform = false;
+        if (ustride < l16 || (ustride & 15u) || ustride >= (1ull << 31)) uniform = false;
+        for (uint64_t k = 0; uniform && k < n_pkts; k++)
+            if (pkt_len[k] != pkt_len[0] || pkt_off[k] != pkt_off[0] + k * ustride) uniform = false;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     release_arena(c);
@@ -355,6 +380,7 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
     c->d_off = (const uint64_t *)c->owned_off;
     c->d_len = (const uint32_t *)c->owned_len;
     c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = payload;
+    c->uniform = uniform; c->uni_off0 = pkt_off[0]; c->uni_stride = (uint32_t)ustride; c->uni_len = pkt_len[0];
     return KMPGPU_OK;
 }
 
@@ -371,12 +397,12 @@ int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes
     if (n_pkts == 0) return KMPGPU_OK;
     if (arena_bytes < 16) return fail(KMPGPU_EINVAL, "arena smaller than 16 bytes");
     HIP_TRY(hipMemsetAsync(c->d_err, 0, 2 * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_sum, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_sum, 0, 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(kmp_launch_validate((const uint64_t *)d_pkt_off, (const uint32_t *)d_pkt_len, n_pkts, arena_bytes, c->d_err, c->d_sum, c->stream));
     uint32_t err[2] = {0, 0};
-    unsigned long long sum = 0;
+    unsigned long long info[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&sum, c->d_sum, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(info, c->d_sum, sizeof info, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (err[0] & 1u) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: a payload offset is not 16-byte aligned");
     if (err[0] & 2u) return fail(KMPGPU_EINVAL, "kmpgpu_attach_arena: a payload (padded to 16 B) exceeds the arena");
@@ -384,7 +410,9 @@ int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes
     c->d_arena = (const uint8_t *)d_arena;
     c->d_off = (const uint64_t *)d_pkt_off;
     c->d_len = (const uint32_t *)d_pkt_len;
-    c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = sum;
+    c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = info[0];
+    c->uniform = (err[1] == 0) && info[2] >= 16 && info[2] < (1ull << 31);
+    c->uni_off0 = info[1]; c->uni_stride = (uint32_t)info[2]; c->uni_len = (uint32_t)info[3];
     return KMPGPU_OK;
 }
 

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 import multithreading_string_matching_amd as K  # noqa: E402
 from multithreading_string_matching_amd import _lib  # noqa: E402
 from multithreading_string_matching_amd.matcher import (  # noqa: E402
-    MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_MODE, OPT_NONTEMPORAL, GpuMatcher)
+    KERNEL_AUTO, KERNEL_GENERAL, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_KERNEL, OPT_MODE,
+    OPT_NONTEMPORAL, GpuMatcher)
 
 FIXTURE_KEYS = [
     "udp.pcap:udp", "udp_1000.pcap:udp", "big_udp.pcap:udp", "very_big_udp.pcap:udp",
@@ -32,20 +33,28 @@ def gm():
     m.close()
 
 
-def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=4):
+def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=4, kernel=KERNEL_AUTO):
     gm.set_option(OPT_MODE, mode)
     gm.set_option(OPT_DEPTH, depth)
+    gm.set_option(OPT_KERNEL, kernel)
     gm.set_patterns(patterns)
     gm.load_arena(arena)
-    return gm.scan()[0]
+    out = gm.scan()[0]
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+    return out
 
 
-def check_payloads(gm, oracle, payloads, patterns, modes=(MODE_FILTER, MODE_AUTOMATON), depth=4):
+# (mode, kernel): filter+confirm on the auto-selected kernel (flat streaming for uniform-length
+# arenas), the same forced onto the general one-packet-per-wavefront kernel, and the pure automaton.
+VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL))
+
+
+def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=4):
     arena = K.HostArena.from_payloads(payloads)
     want, _ = oracle.count(arena.bytes, arena.off, arena.len, patterns)
-    for mode in modes:
-        got = gpu_counts(gm, patterns, arena, mode, depth)
-        assert got.tolist() == want.tolist(), (mode, depth, [(p, int(g), int(w)) for p, g, w in zip(patterns, got, want) if g != w][:5])
+    for mode, kernel in variants:
+        got = gpu_counts(gm, patterns, arena, mode, depth, kernel)
+        assert got.tolist() == want.tolist(), (mode, kernel, depth, [(p, int(g), int(w)) for p, g, w in zip(patterns, got, want) if g != w][:5])
     return want
 
 
@@ -89,8 +98,8 @@ def test_kat_vectors(gm, oracle, kat_matcher):
     pats = sorted(by_pat)
     texts = sorted({t for v in by_pat.values() for t, _ in v})
     arena = K.HostArena.from_payloads(texts)
-    for mode in (MODE_FILTER, MODE_AUTOMATON):
-        got = gpu_counts(gm, pats, arena, mode)
+    for mode, kernel in VARIANTS:
+        got = gpu_counts(gm, pats, arena, mode, kernel=kernel)
         want, _ = oracle.count(arena.bytes, arena.off, arena.len, pats)
         assert got.tolist() == want.tolist()
     # and each vector on its own (one payload, one pattern): the reference's exact answers
@@ -132,7 +141,8 @@ def test_overlapping(gm, oracle):
     payloads += [b"ab" * 700, b"aab" * 500, b"abcab" * 321]
     pats = [b"a", b"aa", b"aaa", b"aaaa", b"aaaaa", b"a" * 16, b"a" * 17, b"a" * 99, b"abab", b"ababab", b"aabaab", b"abcabcab", b"ab" * 20]
     want = check_payloads(gm, oracle, payloads, pats)
-    assert int(want[1]) == sum(max(0, len(p) - 1) for p in payloads[:15])       # 'aa' in 'a'*n -> n-1
+    # 'aa' in 'a'*n -> n-1 overlapping matches; 'aab'*500 adds one per repetition
+    assert int(want[1]) == sum(max(0, len(p) - 1) for p in payloads[:15]) + 500
 
 
 def test_nul_rule(gm, oracle):
@@ -149,6 +159,38 @@ def test_nul_rule(gm, oracle):
     two[30] = 0
     payloads.append(bytes(two))
     check_payloads(gm, oracle, payloads, pats)
+
+
+@pytest.mark.parametrize("L", [1, 5, 16, 17, 48, 100, 1000, 1024, 1500, 1504, 2048, 5000])
+def test_uniform_length_arenas_with_nuls(gm, oracle, L):
+    """Equal-length payloads take the flat streaming kernel: several packets per 1 KiB chunk when L
+    is small, packets straddling chunks when L is large; NULs before / inside / after matches."""
+    rng = random.Random(L)
+    pats = [b"ab", b"abc", b"abcab", b"b", b"abcabcabcabcabcab"]
+    payloads = []
+    for k in range(700 if L <= 100 else 160):
+        b = bytearray(rng.choice(b"abc") for _ in range(L))
+        r = rng.random()
+        if r < 0.3:
+            b[rng.randrange(L)] = 0
+        elif r < 0.4:
+            for _ in range(3):
+                b[rng.randrange(L)] = 0
+        elif r < 0.45:
+            b[L - 1] = 0
+        elif r < 0.5:
+            b[0] = 0
+        payloads.append(bytes(b))
+    check_payloads(gm, oracle, payloads, pats)
+    for depth in (2, 3, 5, 6, 8):
+        check_payloads(gm, oracle, payloads[:97], pats[:3], variants=((MODE_FILTER, KERNEL_AUTO),), depth=depth)
+
+
+def test_uniform_length_few_packets(gm, oracle):
+    """Fewer packets than wavefronts, and a run length that does not divide the packet count."""
+    for n in (1, 2, 3, 5, 63, 64, 65, 1000, 8193):
+        payloads = [(b"xyz%05d-" % k) * 13 for k in range(n)]
+        check_payloads(gm, oracle, payloads, [b"xyz00", b"-xyz", b"z"], variants=((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_GENERAL)))
 
 
 def test_high_bit_bytes_and_all_values(gm, oracle):
@@ -252,9 +294,12 @@ def test_synth_device_equals_host_and_oracle(gm, oracle):
     assert np.array_equal(dev, host)
     gm.set_patterns([needle, b"qz", b"a"])
     gm.attach_arena(d_arena, d_off, d_len)
-    got, _ = gm.scan()
     want, _ = oracle.count(host, off, ln, [needle, b"qz", b"a"], threads=8)
-    assert got.tolist() == want.tolist()
+    for kernel in (KERNEL_AUTO, KERNEL_GENERAL):
+        gm.set_option(OPT_KERNEL, kernel)
+        got, _ = gm.scan()
+        assert got.tolist() == want.tolist()
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
     assert int(got[0]) == K.synth_count_planted(sp, n, 1500)
     gm.set_stream(None)
     del d_arena, d_off, d_len
@@ -300,12 +345,15 @@ def test_full_size_property_1m(gm):
     gm.set_patterns([needle])
     gm.attach_arena(d_arena, d_off, d_len)
     assert gm.arena_info() == (n, n * 1500)
-    for nt in (1, 0):
-        for bpc in (8, 3):
-            gm.set_option(OPT_NONTEMPORAL, nt)
-            gm.set_option(OPT_BLOCKS_PER_CU, bpc)
-            got, t = gm.scan()
-            assert int(got[0]) == planted
+    for kernel in (KERNEL_AUTO, KERNEL_GENERAL):
+        for nt in (1, 0):
+            for bpc in (8, 3):
+                gm.set_option(OPT_KERNEL, kernel)
+                gm.set_option(OPT_NONTEMPORAL, nt)
+                gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+                got, t = gm.scan()
+                assert int(got[0]) == planted
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
     gm.set_option(OPT_NONTEMPORAL, 1)
     gm.set_option(OPT_BLOCKS_PER_CU, 8)
     # sharding: three uneven contiguous ranges must add up (mpi_dumping.c:149-157 property)
