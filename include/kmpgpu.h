@@ -61,7 +61,7 @@ typedef struct kmpgpu_match {
 
 /* Option keys for kmpgpu_set_option. */
 #define KMPGPU_OPT_MODE          1   /* 0 auto (filter + KMP verify), 1 KMP automaton only */
-#define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this (default 8)           */
+#define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this; 0 = auto (default)    */
 #define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8 (default 4) */
 #define KMPGPU_OPT_FUSED         4   /* 1 = one pass for all patterns when available       */
 #define KMPGPU_OPT_KERNEL        5   /* 0 auto (flat streaming kernel when every payload has the

@@ -347,7 +347,16 @@ kmp_scan_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ 
  *     text[s : s+m] == pattern         (a NUL inside the window fails here: patterns are NUL-free)
  * ============================================================================================== */
 
-/* Candidate test for the 16 start offsets of a lane, VALU only: min over (dword ^ first). */
+/* v_min3_u32: written as asm because hipcc re-associates min(a, min(b, c)) chains into extra v_min_u32 */
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+/* Candidate test for the 16 start offsets of a lane, VALU only: min over (dword ^ first);
+ * 12 v_alignbyte + 16 v_xor + 8 v_min3 and no scalar work. */
 template <bool MASKED>
 __device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t first, uint32_t mask)
 {
@@ -360,19 +369,41 @@ __device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t 
         uint32_t x2 = __builtin_amdgcn_alignbyte(hi, lo, 2) ^ first;
         uint32_t x3 = __builtin_amdgcn_alignbyte(hi, lo, 3) ^ first;
         if (MASKED) { x0 &= mask; x1 &= mask; x2 &= mask; x3 &= mask; }
-        acc = min(acc, min(x0, x1));
-        acc = min(acc, min(x2, x3));
+        acc = min3u(acc, x0, x1);
+        acc = min3u(acc, x2, x3);
     }
     return acc;                 /* 0 iff some start offset of this lane shows the pattern's first bytes */
 }
 
+/* ballot of a lane predicate: the compare's SGPR pair itself, no VALU select */
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+
+/* 128-bit buffer resource (raw buffer, stride 0) over [base, base + bytes): loads past the end
+ * return zeros, so the tail chunk needs neither address clamping nor lane masks -- a zero lane can
+ * never be a candidate (patterns are NUL-free) and only ends a packet that ends there anyway. */
+__device__ __forceinline__ i32x4 make_rsrc(const uint8_t *base, uint32_t bytes)
+{
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    i32x4 r;
+    r.x = (int32_t)sgpr((uint32_t)p);
+    r.y = (int32_t)sgpr((uint32_t)(p >> 32) & 0xFFFFu);
+    r.z = (int32_t)sgpr(bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+/* buffer_load_dwordx4 vdst, voffset, srsrc, soffset offen: per-lane offset is a loop constant,
+ * the chunk offset lives in an SGPR -- no vector arithmetic per load.  Same asm rules as
+ * ring_issue (destination only read after a ring_wait naming it). */
 template <bool NT>
-__device__ __forceinline__ void flat_issue(u32x4 &dst, const uint8_t *__restrict__ base, uint32_t vo)
+__device__ __forceinline__ void flat_issue(u32x4 &dst, i32x4 rsrc, uint32_t vo, uint32_t so)
 {
     if (NT)
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
     else
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
 }
 
 /* KMP automaton for the flat kernel: lane scans the text from its own first byte; it stops at a
@@ -403,7 +434,8 @@ __device__ __forceinline__ void automaton_flat(uint4 cur, uint4 nxt, bool act, u
     }
 }
 
-template <int DEPTH, bool MASKED, bool NT>
+/* ABL (tuning only): 0 normal, 1 loads + waits only (no matching work), 2 matching work only (ring never refilled). */
+template <int DEPTH, bool MASKED, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
                      uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
@@ -422,92 +454,124 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+    /* pattern bytes 4..19 and their masks, for the direct confirmation of candidates (m <= 20) */
+    uint32_t pd[4], pm[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t lo = 4u * (uint32_t)(d + 1);
+        pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
+        pm[d] = (m >= lo + 4u) ? 0xFFFFFFFFu : (m <= lo) ? 0u : ((1u << (8u * (m - lo))) - 1u);
+    }
 
     /* this wavefront's packets [k0, k1) = bytes [0, range) behind base */
     const uint64_t k0 = gw * pkts_per_wave;
     const uint64_t k1 = min(n_pkts, k0 + pkts_per_wave);
     const uint32_t range = (k0 < n_pkts) ? (uint32_t)(k1 - k0) * stride : 0u;      /* host guarantees < 2^31 */
     const uint8_t *base = arena + ((k0 < n_pkts) ? k0 * (uint64_t)stride : 0ull);
-    const uint32_t nchunks = (range + KMP_CHUNK - 1u) / KMP_CHUNK;
-    const uint32_t last_vo = range ? range - KMP_LANE_BYTES : 0u;                    /* clamp target of the tail chunk */
     const uint32_t step_mod = KMP_CHUNK % stride;                                    /* p0 advance per chunk (mod stride) */
 
     uint32_t cnt = 0u;
-    if (nchunks) {
+    if (range) {
+        const i32x4    rsrc = make_rsrc(base, range);
         const uint32_t vo0 = lane * KMP_LANE_BYTES;
         u32x4 buf[DEPTH];
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], base, min(vo0 + (uint32_t)s * KMP_CHUNK, last_vo));
+        for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
 
         uint32_t p0 = vo0 % stride;          /* offset of this lane's first byte inside its packet's slot */
         bool     dead = false;               /* the packet that enters the chunk already had a 0x00      */
         uint32_t cb = 0u;                    /* byte offset of the chunk being consumed                   */
-        uint32_t j = 0u;                     /* its index                                                 */
 
-        while (j < nchunks) {
+        while (cb < range) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
-                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
-                if (j < nchunks) {
+                if (ABL != 2) ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (ABL == 1) {
+                    asm volatile("" ::"v"(buf[s]));
+                } else if (cb < range) {
                     const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
-                    const u32x4    bn  = buf[(s + 1) % DEPTH];
-                    const bool     has_next = (j + 1u < nchunks);
-                    const uint4    vn  = has_next ? make_uint4(bn.x, bn.y, bn.z, bn.w) : make_uint4(0u, 0u, 0u, 0u);
-                    const bool     inr = (cb + vo0) < range;                  /* lane holds bytes of the range */
-                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(vn.x))};
+                    const u32x4    bn  = buf[(s + 1) % DEPTH];                /* next chunk (zeros past the range) */
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
                     const uint32_t fm = filter_min<MASKED>(w, first, mask);
-                    const uint64_t zl = __ballot(inr && zm != 0u);            /* lanes holding a 0x00           */
-                    const uint64_t st = __ballot(inr && p0 == 0u);            /* lanes where a packet starts    */
-                    const uint64_t cl = __ballot(inr && fm == 0u);            /* lanes with a candidate         */
+                    const uint64_t zl = ballot64(zm != 0u);                   /* lanes holding a 0x00           */
+                    const uint64_t st = ballot64(p0 == 0u);                   /* lanes where a packet starts    */
+                    const uint64_t cl = ballot64(fm == 0u);                   /* lanes with a candidate         */
                     const bool dead_in = dead;
-                    /* carry for the next chunk: zeros at or after the last packet start of this chunk */
-                    if (st == 0ull) dead = dead || (zl != 0ull);
-                    else            dead = (zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull;
+                    /* carry for the next chunk: is there a 0x00 at or after the last packet start of this chunk? */
+                    if (zl == 0ull) { if (st != 0ull) dead = false; }
+                    else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
 
                     if (cl != 0ull) {
-                        /* rare path.  Has the packet of this lane a 0x00 before the lane's bytes? */
-                        const uint64_t below = (1ull << lane) - 1ull;
-                        const uint64_t st_le = st & (below | (1ull << lane));
-                        bool nul_before;
-                        if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
-                        else {
-                            const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
-                            nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
+                        /* rare path.  maxi = largest start index (0..15) of this lane that still counts:
+                         * window inside the payload, no 0x00 before it, lane has a candidate at all. */
+                        int32_t maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
+                        if (fm != 0u) maxi = -1;
+                        if (zl != 0ull || dead_in) {
+                            const uint64_t below = (1ull << lane) - 1ull;
+                            const uint64_t st_le = st & (below | (1ull << lane));
+                            bool nul_before;
+                            if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
+                            else {
+                                const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
+                                nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
+                            }
+                            /* index of the first 0x00 inside the lane's own 16 bytes (16 = none) */
+                            const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
+                            uint32_t zi = 16u;
+                            if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
+                            if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
+                            if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
+                            if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
+                            maxi = nul_before ? -1 : min(maxi, (int32_t)zi - 1);
                         }
-                        /* index of the first 0x00 inside the lane's own 16 bytes (16 = none) */
-                        const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
-                        uint32_t zi = 16u;
-                        if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
-                        if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
-                        if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
-                        if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
-                        const bool lane_ok = inr && (fm == 0u) && !nul_before;
+                        const uint64_t ba = ballot64(maxi >= 0);
                         if (m <= 4u) {
+                            /* the filter compared all m bytes */
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const uint32_t lo = w[q], hi = w[q + 1];
 #pragma unroll
                                 for (int a = 0; a < 4; ++a) {
-                                    const uint32_t i = (uint32_t)(4 * q + a);
-                                    const uint32_t d = a ? __builtin_amdgcn_alignbyte(hi, lo, a) : lo;
-                                    if (lane_ok && is_cand<MASKED>(d, first, mask) && (i < zi) && (p0 + i + m <= L)) ++cnt;
+                                    const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
+                                    cnt += (is_cand<MASKED>(d0, first, mask) && (4 * q + a) <= maxi) ? 1u : 0u;
                                 }
                             }
-                        } else {
-                            const bool act = lane_ok && (p0 + m <= L);
-                            if (__ballot(act) != 0ull) automaton_flat(v, vn, act, p0, L, m, s_pat, cnt);
+                        } else if (ba != 0ull) {
+                            if (m <= 20u && __builtin_popcountll(ba) <= 16) {
+                                /* few candidates: compare the rest of the pattern dword-wise, straight from
+                                 * registers.  W[0..8] = the lane's 16 bytes + the next 20 of the stream. */
+                                const uint32_t W[10] = {w[0], w[1], w[2], w[3], w[4], wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
+                                                        wave_shl1(v.w, sgpr(bn.w)),
+                                                        wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                                    for (int a = 0; a < 4; ++a) {
+                                        const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
+                                        bool ok = (d0 == first) && (4 * q + a) <= maxi;
+                                        if (ballot64(ok) != 0ull) {
+#pragma unroll
+                                            for (int d = 0; d < 4; ++d) {
+                                                const uint32_t t = a ? __builtin_amdgcn_alignbyte(W[q + d + 2], W[q + d + 1], a) : W[q + d + 1];
+                                                ok = ok && (((t ^ pd[d]) & pm[d]) == 0u);
+                                            }
+                                            cnt += ok ? 1u : 0u;
+                                        }
+                                    }
+                                }
+                            } else {
+                                automaton_flat(v, make_uint4(bn.x, bn.y, bn.z, bn.w), maxi >= 0, p0, L, m, s_pat, cnt);
+                            }
                         }
                     }
-                    /* advance to the next chunk */
+                    /* this lane's position inside its packet, one chunk further */
                     p0 += step_mod;
                     p0 = min(p0, p0 - stride);               /* unsigned: subtracts stride iff p0 >= stride */
-                    cb += KMP_CHUNK;
-                    ++j;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                flat_issue<NT>(buf[s], base, min(vo0 + cb + (uint32_t)(DEPTH - 1) * KMP_CHUNK, last_vo));
+                if (ABL != 2) flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
+                cb += KMP_CHUNK;
             }
         }
 #pragma unroll
@@ -655,7 +719,13 @@ template <int DEPTH, bool MASKED>
 hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
 {
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
-    if (a.nontemporal)
+    if (a.ablate == 1 && DEPTH == 4 && !MASKED)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 1>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
+                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+    else if (a.ablate == 2 && DEPTH == 4 && !MASKED)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 2>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
+                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+    else if (a.nontemporal)
         hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
                            a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
     else

@@ -25,6 +25,7 @@ struct kmp_scan_args {
     uint32_t               uniform_stride;
     uint32_t               uniform_len;
     uint32_t               pkts_per_wave;
+    int                    ablate;       /* tuning only: 1 memory-only, 2 compute-only variants of the flat kernel */
 };
 
 hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st);

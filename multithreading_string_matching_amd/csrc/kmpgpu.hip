@@ -84,7 +84,7 @@ struct kmpgpu_ctx {
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 8, depth = 4, nontemporal = 1, kernel_sel = 0;
+    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, ablate = 0;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -96,10 +96,15 @@ struct kmpgpu_ctx {
 
 namespace {
 
+bool use_flat(const kmpgpu_ctx *c) { return c->uniform && c->kernel_sel == 0 && c->mode == 0; }
+
 uint32_t grid_blocks(const kmpgpu_ctx *c)
 {
+    /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat streaming kernel (it is
+     * HBM-bound from 2 blocks/CU on) and 8 for the general kernel */
+    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : (use_flat(c) ? 4 : 8);
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
-    uint64_t cap = (uint64_t)c->cu_count * (uint64_t)c->blocks_per_cu;
+    uint64_t cap = (uint64_t)c->cu_count * (uint64_t)bpc;
     uint64_t b = std::min(need, cap);
     return (uint32_t)std::max<uint64_t>(b, 1);
 }
@@ -145,10 +150,11 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
     a.arena = c->d_arena; a.pkt_off = c->d_off; a.pkt_len = c->d_len; a.n_pkts = c->n_pkts;
     a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; a.mode = c->mode;
     a.nontemporal = c->nontemporal != 0;
+    a.ablate = c->ablate;
     /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
     const uint64_t nwaves = (uint64_t)bx * KMP_BLOCK_WAVES;
     const uint64_t ppw = (c->n_pkts + nwaves - 1) / nwaves;
-    const bool flat = c->uniform && c->kernel_sel == 0 && c->mode == 0 && ppw * c->uni_stride < (1ull << 31);
+    const bool flat = use_flat(c) && ppw * c->uni_stride < (1ull << 31);
     if (flat) {
         a.arena = c->d_arena + c->uni_off0;
         a.uniform_stride = c->uni_stride; a.uniform_len = c->uni_len; a.pkts_per_wave = (uint32_t)ppw;
@@ -258,7 +264,7 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
         if (value != 0 && value != 1) return fail(KMPGPU_EINVAL, "mode must be 0 or 1");
         c->mode = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_BLOCKS_PER_CU:
-        if (value < 1 || value > 64) return fail(KMPGPU_EINVAL, "blocks per CU must be 1..64");
+        if (value < 0 || value > 64) return fail(KMPGPU_EINVAL, "blocks per CU must be 0 (auto) or 1..64");
         c->blocks_per_cu = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_DEPTH:
         if (value < 2 || value > 8 || value == 7) return fail(KMPGPU_EINVAL, "depth must be 2..6 or 8");
@@ -268,6 +274,8 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
     case KMPGPU_OPT_KERNEL:
         if (value != 0 && value != 1) return fail(KMPGPU_EINVAL, "kernel selection must be 0 or 1");
         c->kernel_sel = (int)value; return KMPGPU_OK;
+    case 101:                   /* undocumented, tuning only: ablation variants of the flat kernel (results are wrong) */
+        c->ablate = (int)value; return KMPGPU_OK;
     case 100:                   /* undocumented: 0 = default cache policy loads, 1 = non-temporal */
         c->nontemporal = value ? 1 : 0; return KMPGPU_OK;
     default:

@@ -85,7 +85,7 @@ def test_depths_and_grids(gm, oracle, tokens, depth):
         gm.set_option(OPT_BLOCKS_PER_CU, bpc)
         got = gpu_counts(gm, tokens, arena, MODE_FILTER, depth)
         assert got.tolist() == want.tolist()
-    gm.set_option(OPT_BLOCKS_PER_CU, 8)
+    gm.set_option(OPT_BLOCKS_PER_CU, 0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -355,7 +355,7 @@ def test_full_size_property_1m(gm):
                 assert int(got[0]) == planted
     gm.set_option(OPT_KERNEL, KERNEL_AUTO)
     gm.set_option(OPT_NONTEMPORAL, 1)
-    gm.set_option(OPT_BLOCKS_PER_CU, 8)
+    gm.set_option(OPT_BLOCKS_PER_CU, 0)
     # sharding: three uneven contiguous ranges must add up (mpi_dumping.c:149-157 property)
     total = 0
     for lo, hi in ((0, 333_334), (333_334, 666_667), (666_667, n)):
