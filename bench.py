@@ -37,6 +37,31 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: the scheduler affinity capped by the cgroup CPU
+    quota (a GPU box exposes all 256 logical CPUs but grants a 16-CPU share)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, -(-q // p)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,11 +181,7 @@ def main() -> None:
         host = d_arena.cpu().numpy()
         off = d_off.cpu().numpy().astype(np.uint64)
         ln = d_len.cpu().numpy().astype(np.uint32)
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            pass
+        cores = host_cores()
         best = None
         for _ in range(max(1, args.cpu_reps)):
             counts, dt = o.count(host, off, ln, [NEEDLE], threads=cores)
