@@ -200,9 +200,11 @@ def main() -> None:
         bytes_all = payload_bytes * world * args.steps
         value = bytes_all / elapsed / 1e9
         achieved = payload_bytes / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 on gfx950, own rocprofv3 pass,
+        # profiles/roofline_traffic.json); only valid for the workload it was collected on
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.isfile(tpath):
+        if os.path.isfile(tpath) and n == 1_000_000:
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
@@ -222,7 +224,7 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "kmp_scan_kernel", "launch_ms_avg": round(avg_launch_ms, 5),
+                "kernel": "kmp_scan_flat_kernel", "launch_ms_avg": round(avg_launch_ms, 5),
                 "algorithmic_bytes_per_launch": payload_bytes,
             },
             "cpu_baseline": cpu,
