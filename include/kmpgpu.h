@@ -64,9 +64,12 @@ typedef struct kmpgpu_match {
 #define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this; 0 = auto (default)    */
 #define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8 (default 4) */
 #define KMPGPU_OPT_FUSED         4   /* 1 = one pass for all patterns when available       */
-#define KMPGPU_OPT_KERNEL        5   /* 0 auto (flat streaming kernel when every payload has the
-                                        same length and the slots are back to back), 1 always
-                                        the general one-packet-per-wavefront kernel             */
+#define KMPGPU_OPT_KERNEL        5   /* 0 auto: flat streaming kernel when every payload has the
+                                        same length and the slots are back to back, packed
+                                        streaming kernel when the slots are back to back with
+                                        mixed lengths, else the general kernel; 1 always the
+                                        general one-packet-per-wavefront kernel; 2 the packed
+                                        streaming kernel whenever the slots are back to back   */
 
 const char *kmpgpu_last_error(void);
 int  kmpgpu_device_count(void);                        /* >= 0, or KMPGPU_EHIP                */

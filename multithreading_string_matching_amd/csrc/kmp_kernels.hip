@@ -591,6 +591,214 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
     }
 }
 
+/* ================================================================================================
+ * Packed arenas of arbitrary payload lengths (real captures, mixed-length traffic): the same flat
+ * streaming as above, with the two things the uniform kernel gets from arithmetic taken from small
+ * side tables built once when the arena is loaded:
+ *   - bitmap: one bit per 16-byte slot of the arena, set where a payload starts (0.8 % of the arena
+ *     size); the 64 bits of a chunk ARE the packet-start ballot, fetched by one scalar load per chunk;
+ *   - plan: per wavefront the first packet index and byte offset of its range.  Ranges are cut at
+ *     packet starts at equal BYTE distance, which is the load balancing for mixed lengths
+ *     (BASELINE configs[4]): every wavefront streams the same number of bytes whatever the lengths.
+ * Lanes learn their packet (index, offset, length) only on the rare path, from the start ballot:
+ * packet index = packets started before this chunk + starts at lanes <= own lane.
+ * ============================================================================================== */
+struct kmp_plan_entry { uint64_t k; uint64_t off; };
+
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_build_bitmap_kernel(const uint64_t *__restrict__ pkt_off, uint64_t n, unsigned long long *__restrict__ bitmap)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t slot = pkt_off[k] >> 4;
+        atomicOr(bitmap + (slot >> 6), 1ull << (slot & 63ull));
+    }
+}
+
+/* plan[w] = first packet whose offset is >= off[0] + w * bytes_per_wave (w = 0..nwaves); plan[nwaves] = {n, end}. */
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len, uint64_t n, uint64_t nwaves,
+                uint64_t bytes_per_wave, kmp_plan_entry *__restrict__ plan)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > nwaves) return;
+    const uint64_t l16 = ((uint64_t)pkt_len[n - 1] + 15ull) & ~15ull;
+    const uint64_t end = pkt_off[n - 1] + (l16 < 16ull ? 16ull : l16);
+    if (w == nwaves) { plan[w].k = n; plan[w].off = end; return; }
+    const uint64_t target = pkt_off[0] + w * bytes_per_wave;
+    uint64_t lo = 0, hi = n;                       /* lower_bound over the (increasing) offsets */
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pkt_off[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    plan[w].k = lo;
+    plan[w].off = (lo < n) ? pkt_off[lo] : end;
+}
+
+template <int DEPTH, bool MASKED, bool NT>
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
+                       const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,
+                       const kmp_plan_entry *__restrict__ plan, const kmp_pattern_dev *__restrict__ patterns,
+                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials)
+{
+    __shared__ kmp_pattern_dev s_pat;
+    __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
+
+    const uint32_t pid = pat_ids[blockIdx.y];
+    const kmp_pattern_dev *gp = patterns + pid;
+    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
+        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
+    __syncthreads();
+
+    const uint32_t m = gp->m, first = gp->first, mask = gp->mask;
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint32_t wave = sgpr(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+    uint32_t pd[4], pm[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t lo = 4u * (uint32_t)(d + 1);
+        pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
+        pm[d] = (m >= lo + 4u) ? 0xFFFFFFFFu : (m <= lo) ? 0u : ((1u << (8u * (m - lo))) - 1u);
+    }
+
+    const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
+    const uint64_t off0 = plan[gw].off;
+    const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;    /* planner guarantees < 2^31 */
+
+    uint32_t cnt = 0u;
+    if (range) {
+        const uint8_t *base = arena + off0;
+        const i32x4    rsrc = make_rsrc(base, range);
+        const uint32_t vo0 = lane * KMP_LANE_BYTES;
+        /* packet-start bits of chunk j: bits [b0 + 64 j, +64) of the bitmap = words wi0+j, wi0+j+1 shifted by sh */
+        const uint64_t b0 = off0 >> 4;
+        const unsigned long long *bw = bitmap + (b0 >> 6);
+        const uint32_t sh = (uint32_t)(b0 & 63ull);
+
+        u32x4 buf[DEPTH];
+        unsigned long long hiw[DEPTH];       /* bitmap word wi0 + j + 1 of the chunk in ring slot s */
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+            hiw[s] = bw[s + 1];
+        }
+        unsigned long long low = bw[0];      /* bitmap word wi0 + j of the chunk being consumed */
+        uint64_t kbase = k0 - 1ull;          /* index of the last packet started before the chunk */
+        bool     dead = false;
+        uint32_t cb = 0u, j = 0u;
+
+        while (cb < range) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (cb < range) {
+                    const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    const u32x4    bn  = buf[(s + 1) % DEPTH];
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
+                    const unsigned long long hi = hiw[s];
+                    const uint64_t st = sh ? ((low >> sh) | (hi << (64u - sh))) : low;   /* lanes where a packet starts */
+                    low = hi;
+
+                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
+                    const uint32_t fm = filter_min<MASKED>(w, first, mask);
+                    const uint64_t zl = ballot64(zm != 0u);
+                    const uint64_t cl = ballot64(fm == 0u);
+                    const bool dead_in = dead;
+                    if (zl == 0ull) { if (st != 0ull) dead = false; }
+                    else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
+
+                    if (cl != 0ull) {
+                        /* rare path: which packet does a candidate lane sit in? */
+                        int32_t  maxi = -1;
+                        uint32_t p0 = 0u, L = 0u;
+                        if (fm == 0u) {
+                            const uint64_t le = (2ull << lane) - 1ull;                  /* lanes <= own (lane 63: all ones) */
+                            const uint64_t kl = kbase + (uint64_t)__builtin_popcountll(st & le);
+                            const uint64_t po = pkt_off[kl];
+                            L  = pkt_len[kl];
+                            p0 = (uint32_t)(off0 + cb + vo0 - po);
+                            maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
+                        }
+                        if (zl != 0ull || dead_in) {
+                            const uint64_t below = (1ull << lane) - 1ull;
+                            const uint64_t st_le = st & (below | (1ull << lane));
+                            bool nul_before;
+                            if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
+                            else {
+                                const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
+                                nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
+                            }
+                            const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
+                            uint32_t zi = 16u;
+                            if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
+                            if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
+                            if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
+                            if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
+                            maxi = nul_before ? -1 : min(maxi, (int32_t)zi - 1);
+                        }
+                        const uint64_t ba = ballot64(maxi >= 0);
+                        if (m <= 4u) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                                for (int a = 0; a < 4; ++a) {
+                                    const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
+                                    cnt += (is_cand<MASKED>(d0, first, mask) && (4 * q + a) <= maxi) ? 1u : 0u;
+                                }
+                            }
+                        } else if (ba != 0ull) {
+                            if (m <= 20u && __builtin_popcountll(ba) <= 16) {
+                                const uint32_t W[10] = {w[0], w[1], w[2], w[3], w[4], wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
+                                                        wave_shl1(v.w, sgpr(bn.w)),
+                                                        wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                                    for (int a = 0; a < 4; ++a) {
+                                        const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
+                                        bool ok = (d0 == first) && (4 * q + a) <= maxi;
+                                        if (ballot64(ok) != 0ull) {
+#pragma unroll
+                                            for (int d = 0; d < 4; ++d) {
+                                                const uint32_t t = a ? __builtin_amdgcn_alignbyte(W[q + d + 2], W[q + d + 1], a) : W[q + d + 1];
+                                                ok = ok && (((t ^ pd[d]) & pm[d]) == 0u);
+                                            }
+                                            cnt += ok ? 1u : 0u;
+                                        }
+                                    }
+                                }
+                            } else {
+                                automaton_flat(v, make_uint4(bn.x, bn.y, bn.z, bn.w), maxi >= 0, p0, L, m, s_pat, cnt);
+                            }
+                        }
+                    }
+                    kbase += (uint64_t)__builtin_popcountll(st);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
+                hiw[s] = bw[j + (uint32_t)DEPTH + 1u];
+                cb += KMP_CHUNK;
+                ++j;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+    }
+
+    unsigned long long c64 = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+    if (lane == 0u) s_wave_cnt[wave] = c64;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) t += s_wave_cnt[i];
+        partials[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 /* counts[pat_ids[y]] = sum of that pattern's block partials. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t blocks_x,
@@ -612,8 +820,9 @@ kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t bloc
 }
 
 /* Layout contract of kmpgpu.h for a device-resident index: err[0] |= 1 misaligned, |= 2 out of
- * bounds, |= 4 length >= 2^30; err[1] != 0: the arena is NOT uniform-stride; info[0] += sum(len),
- * info[1..3] = offset of payload 0, stride (offset 1 - offset 0), length of payload 0. */
+ * bounds, |= 4 length >= 2^30; err[1] & 1: the arena is NOT uniform-stride, err[1] & 2: slots are NOT
+ * packed back to back; info[0] += sum(len),
+ * info[1..4] = offset of payload 0, stride (offset 1 - offset 0), length of payload 0, end of the last slot. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len, uint64_t n,
                           uint64_t arena_bytes, uint32_t *__restrict__ err, unsigned long long *__restrict__ info)
@@ -625,7 +834,7 @@ kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *
     const uint32_t len0 = pkt_len[0];
     const uint64_t l016 = ((uint64_t)len0 + 15ull) & ~15ull;
     const uint64_t stride = (n > 1) ? pkt_off[1] - off0 : (l016 < 16ull ? 16ull : l016);
-    if ((n > 1 && pkt_off[1] < off0) || stride < (l016 < 16ull ? 16ull : l016) || (stride & 15ull)) nonuni = 1u;
+    if ((n > 1 && pkt_off[1] < off0) || stride < (l016 < 16ull ? 16ull : l016) || (stride & 15ull)) nonuni |= 1u;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t o = pkt_off[k];
         const uint64_t l = pkt_len[k];
@@ -633,11 +842,12 @@ kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *
         if (l >= (1ull << 30)) e |= 4u;
         const uint64_t l16 = (l + 15ull) & ~15ull;
         if (o > arena_bytes || (l16 < 16ull ? 16ull : l16) > arena_bytes - o) e |= 2u;   /* every payload owns >= 16 readable bytes */
-        if (l != len0 || o != off0 + k * stride) nonuni = 1u;
+        if (l != len0 || o != off0 + k * stride) nonuni |= 1u;
+        if (k + 1 < n && pkt_off[k + 1] != o + (l16 < 16ull ? 16ull : l16)) nonuni |= 2u;      /* not packed back to back */
         sum += l;
     }
     if (e) atomicOr(err, e);
-    if (nonuni) atomicOr(err + 1, 1u);
+    if (nonuni) atomicOr(err + 1, nonuni);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((threadIdx.x & 63u) == 0u) s[threadIdx.x >> 6] = sum;
@@ -646,7 +856,11 @@ kmp_validate_index_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *
         unsigned long long r = 0ull;
         for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) r += s[i];
         atomicAdd(info, r);
-        if (blockIdx.x == 0u) { info[1] = off0; info[2] = stride; info[3] = len0; }
+        if (blockIdx.x == 0u) {
+            info[1] = off0; info[2] = stride; info[3] = len0;
+            const uint64_t ll16 = ((uint64_t)pkt_len[n - 1] + 15ull) & ~15ull;
+            info[4] = pkt_off[n - 1] + (ll16 < 16ull ? 16ull : ll16);
+        }
     }
 }
 
@@ -746,6 +960,52 @@ hipError_t launch_flat_d(const kmp_scan_args &a, hipStream_t st)
     }
 }
 }  // namespace
+
+namespace {
+template <int DEPTH, bool MASKED>
+hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
+{
+    dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
+    const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
+    if (a.nontemporal)
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, true>), grid, block, 0, st, a.arena, a.pkt_off, a.pkt_len, a.bitmap,
+                           plan, a.patterns, a.pat_ids, a.partials);
+    else
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, false>), grid, block, 0, st, a.arena, a.pkt_off, a.pkt_len, a.bitmap,
+                           plan, a.patterns, a.pat_ids, a.partials);
+    return hipGetLastError();
+}
+}  // namespace
+
+/* Flat streaming kernel for packed arenas of arbitrary payload lengths (bitmap + plan from kmp_launch_prepare_packed). */
+hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st)
+{
+    if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
+    switch (a.depth) {
+    case 3: return a.masked ? launch_packed_t<3, true>(a, st) : launch_packed_t<3, false>(a, st);
+    case 6: return a.masked ? launch_packed_t<6, true>(a, st) : launch_packed_t<6, false>(a, st);
+    default: return a.masked ? launch_packed_t<4, true>(a, st) : launch_packed_t<4, false>(a, st);
+    }
+}
+
+hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned long long *bitmap, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS;
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(kmp_build_bitmap_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, pkt_off, n, bitmap);
+    return hipGetLastError();
+}
+
+hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
+                           void *plan, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (nwaves + 1 + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS;
+    hipLaunchKernelGGL(kmp_plan_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, pkt_off, pkt_len, n, nwaves,
+                       bytes_per_wave, reinterpret_cast<kmp_plan_entry *>(plan));
+    return hipGetLastError();
+}
 
 /* Flat streaming kernel for uniform-stride arenas (a.arena already points at payload 0). */
 hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st)

@@ -25,11 +25,18 @@ struct kmp_scan_args {
     uint32_t               uniform_stride;
     uint32_t               uniform_len;
     uint32_t               pkts_per_wave;
+    /* packed kernel only */
+    const unsigned long long *bitmap;   /* one bit per 16-byte slot of the arena: a payload starts here */
+    const void            *plan;         /* kmp_plan_entry[waves + 1]                                   */
     int                    ablate;       /* tuning only: 1 memory-only, 2 compute-only variants of the flat kernel */
 };
 
 hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st);
 hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st);
+hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st);
+hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned long long *bitmap, hipStream_t st);
+hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
+                           void *plan, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,

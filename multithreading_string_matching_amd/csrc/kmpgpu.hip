@@ -70,6 +70,11 @@ struct kmpgpu_ctx {
     const uint32_t *d_len = nullptr;
     uint64_t        arena_bytes = 0, n_pkts = 0, payload_bytes = 0;
     bool            uniform = false;                  /* every payload has the same length, slots back to back */
+    bool            packed = false;                   /* slots back to back (any lengths): flat streaming with bitmap + plan */
+    uint64_t        span_end = 0;                     /* end offset of the last slot */
+    unsigned long long *d_bitmap = nullptr;           /* one bit per 16-byte slot: a payload starts here */
+    void           *d_plan = nullptr;                 /* kmp_plan_entry[plan_waves + 1] */
+    uint64_t        plan_waves = 0, plan_cap = 0;
     uint64_t        uni_off0 = 0;
     uint32_t        uni_stride = 0, uni_len = 0;
     void           *owned_arena = nullptr, *owned_off = nullptr, *owned_len = nullptr;
@@ -79,7 +84,7 @@ struct kmpgpu_ctx {
     size_t              partials_cap = 0;             /* elements */
     unsigned long long *d_counts = nullptr;
     uint32_t           *d_err = nullptr;              /* [2] validation flags */
-    unsigned long long *d_sum = nullptr;              /* [4] payload bytes, offset 0, stride, length 0 */
+    unsigned long long *d_sum = nullptr;              /* [6] payload bytes, offset 0, stride, length 0, end of last slot */
     uint64_t           *h_counts = nullptr;           /* pinned */
     size_t              h_counts_cap = 0;
 
@@ -97,12 +102,16 @@ struct kmpgpu_ctx {
 namespace {
 
 bool use_flat(const kmpgpu_ctx *c) { return c->uniform && c->kernel_sel == 0 && c->mode == 0; }
+bool use_packed(const kmpgpu_ctx *c)
+{
+    return c->packed && c->d_bitmap && c->mode == 0 && (c->kernel_sel == 2 || (c->kernel_sel == 0 && !c->uniform));
+}
 
 uint32_t grid_blocks(const kmpgpu_ctx *c)
 {
     /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat streaming kernel (it is
      * HBM-bound from 2 blocks/CU on) and 8 for the general kernel */
-    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : (use_flat(c) ? 4 : 8);
+    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : ((use_flat(c) || use_packed(c)) ? 4 : 8);
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
     uint64_t cap = (uint64_t)c->cu_count * (uint64_t)bpc;
     uint64_t b = std::min(need, cap);
@@ -127,7 +136,21 @@ void release_arena(kmpgpu_ctx *c)
     c->owned_arena = c->owned_off = c->owned_len = nullptr;
     c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
     c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
-    c->uniform = false;
+    c->uniform = false; c->packed = false; c->plan_waves = 0;
+    if (c->d_bitmap) (void)hipFree(c->d_bitmap);
+    c->d_bitmap = nullptr;
+}
+
+/* Side tables of the packed streaming kernel: start bitmap now, wavefront plan on first use. */
+int prepare_packed(kmpgpu_ctx *c)
+{
+    if (!c->packed || c->n_pkts == 0) return KMPGPU_OK;
+    const size_t words = (size_t)(c->arena_bytes / KMP_CHUNK) + 16;      /* ring prefetch reads up to 8 words past the end */
+    HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->d_bitmap, 0, words * sizeof(unsigned long long), c->stream));
+    HIP_TRY(kmp_launch_build_bitmap(c->d_off, c->n_pkts, c->d_bitmap, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return KMPGPU_OK;
 }
 
 /* Enqueue one full pass: scan launches (patterns grouped by "shorter than 4 bytes") + reduce. */
@@ -159,6 +182,26 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
         a.arena = c->d_arena + c->uni_off0;
         a.uniform_stride = c->uni_stride; a.uniform_len = c->uni_len; a.pkts_per_wave = (uint32_t)ppw;
     }
+    /* packed arenas of mixed lengths: byte-balanced wavefront ranges (plan) + packet-start bitmap */
+    bool packed = !flat && use_packed(c);
+    if (packed) {
+        const uint64_t span = c->span_end - c->uni_off0;
+        const uint64_t bpw = (((span + nwaves - 1) / nwaves) + 15ull) & ~15ull;
+        if (bpw >= (1ull << 30)) packed = false;
+        else {
+            if (c->plan_waves != nwaves) {
+                if (c->plan_cap < nwaves + 1) {
+                    if (c->d_plan) HIP_TRY(hipFree(c->d_plan));
+                    c->d_plan = nullptr; c->plan_cap = 0;
+                    HIP_TRY(hipMalloc(&c->d_plan, (nwaves + 1) * 16));
+                    c->plan_cap = nwaves + 1;
+                }
+                HIP_TRY(kmp_launch_plan(c->d_off, c->d_len, c->n_pkts, nwaves, bpw ? bpw : 16, c->d_plan, c->stream));
+                c->plan_waves = nwaves;
+            }
+            a.bitmap = c->d_bitmap; a.plan = c->d_plan;
+        }
+    }
 
     struct Group { uint32_t first, n; bool masked; } groups[2] = {{0, c->n_long, false}, {c->n_long, c->n_short, true}};
     for (const Group &g : groups) {
@@ -174,7 +217,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
                 e0 = c->prof_ev[2 * c->prof_n]; e1 = c->prof_ev[2 * c->prof_n + 1];
                 HIP_TRY(hipEventRecord(e0, c->stream));
             }
-            HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : kmp_launch_scan(a, c->stream));
+            HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream));
             ++nl;
@@ -221,7 +264,7 @@ int kmpgpu_init(kmpgpu_ctx **out, int device)
         for (auto &ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     }
     if (e == hipSuccess) e = hipMalloc(&c->d_err, 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_sum, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&c->d_sum, 6 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         kmpgpu_destroy(c);
         return fail(KMPGPU_EHIP, "kmpgpu_init: %s", hipGetErrorString(e));
@@ -240,6 +283,7 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -272,7 +316,7 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
     case KMPGPU_OPT_FUSED:
         return KMPGPU_OK;       /* reserved: fused multi-pattern pass */
     case KMPGPU_OPT_KERNEL:
-        if (value != 0 && value != 1) return fail(KMPGPU_EINVAL, "kernel selection must be 0 or 1");
+        if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "kernel selection must be 0, 1 or 2");
         c->kernel_sel = (int)value; return KMPGPU_OK;
     case 101:                   /* undocumented, tuning only: ablation variants of the flat kernel (results are wrong) */
         c->ablate = (int)value; return KMPGPU_OK;
@@ -356,6 +400,9 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
                         (unsigned long long)o, (unsigned long long)pkt_len[k], (unsigned long long)arena_bytes);
         payload += pkt_len[k];
     }
+    bool packed = n_pkts > 0;
+    for (uint64_t k = 0; packed && k + 1 < n_pkts; k++)
+        if (pkt_off[k + 1] != pkt_off[k] + std::max<uint64_t>(((uint64_t)pkt_len[k] + 15u) & ~15ull, 16)) packed = false;
     bool uniform = n_pkts > 0;
     uint64_t ustride = 0;
     if (uniform) {
@@ -389,7 +436,9 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
     c->d_len = (const uint32_t *)c->owned_len;
     c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = payload;
     c->uniform = uniform; c->uni_off0 = pkt_off[0]; c->uni_stride = (uint32_t)ustride; c->uni_len = pkt_len[0];
-    return KMPGPU_OK;
+    c->packed = packed;
+    c->span_end = pkt_off[n_pkts - 1] + std::max<uint64_t>(((uint64_t)pkt_len[n_pkts - 1] + 15u) & ~15ull, 16);
+    return prepare_packed(c);
 }
 
 int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes, const void *d_pkt_off,
@@ -405,10 +454,10 @@ int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes
     if (n_pkts == 0) return KMPGPU_OK;
     if (arena_bytes < 16) return fail(KMPGPU_EINVAL, "arena smaller than 16 bytes");
     HIP_TRY(hipMemsetAsync(c->d_err, 0, 2 * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_sum, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_sum, 0, 6 * sizeof(unsigned long long), c->stream));
     HIP_TRY(kmp_launch_validate((const uint64_t *)d_pkt_off, (const uint32_t *)d_pkt_len, n_pkts, arena_bytes, c->d_err, c->d_sum, c->stream));
     uint32_t err[2] = {0, 0};
-    unsigned long long info[4] = {0, 0, 0, 0};
+    unsigned long long info[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(info, c->d_sum, sizeof info, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -419,9 +468,11 @@ int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes
     c->d_off = (const uint64_t *)d_pkt_off;
     c->d_len = (const uint32_t *)d_pkt_len;
     c->arena_bytes = arena_bytes; c->n_pkts = n_pkts; c->payload_bytes = info[0];
-    c->uniform = (err[1] == 0) && info[2] >= 16 && info[2] < (1ull << 31);
+    c->uniform = ((err[1] & 1u) == 0) && info[2] >= 16 && info[2] < (1ull << 31);
     c->uni_off0 = info[1]; c->uni_stride = (uint32_t)info[2]; c->uni_len = (uint32_t)info[3];
-    return KMPGPU_OK;
+    c->packed = (err[1] & 2u) == 0;
+    c->span_end = info[4];
+    return prepare_packed(c);
 }
 
 int kmpgpu_scan_enqueue(kmpgpu_ctx *c, void *d_counts_out)

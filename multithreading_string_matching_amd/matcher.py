@@ -19,7 +19,7 @@ from ._lib import KmpGpuError, Match, SynthParams, Timing, gpu_check, u8p, u32p,
 from .host import HostArena
 
 OPT_MODE, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_NONTEMPORAL = 1, 2, 3, 4, 5, 100
-KERNEL_AUTO, KERNEL_GENERAL = 0, 1
+KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED = 0, 1, 2
 MODE_FILTER, MODE_AUTOMATON = 0, 1
 
 

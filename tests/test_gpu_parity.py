@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 import multithreading_string_matching_amd as K  # noqa: E402
 from multithreading_string_matching_amd import _lib  # noqa: E402
 from multithreading_string_matching_amd.matcher import (  # noqa: E402
-    KERNEL_AUTO, KERNEL_GENERAL, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_KERNEL, OPT_MODE,
+    KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_KERNEL, OPT_MODE,
     OPT_NONTEMPORAL, GpuMatcher)
 
 FIXTURE_KEYS = [
@@ -45,8 +45,9 @@ def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=4, kernel=KERNEL_AUT
 
 
 # (mode, kernel): filter+confirm on the auto-selected kernel (flat streaming for uniform-length
-# arenas), the same forced onto the general one-packet-per-wavefront kernel, and the pure automaton.
-VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL))
+# arenas, packed streaming for mixed lengths), the packed streaming kernel forced, the general
+# one-packet-per-wavefront kernel forced, and the pure KMP automaton.
+VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL))
 
 
 def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=4):
@@ -62,12 +63,12 @@ def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=4):
 # golden fixtures
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("key", FIXTURE_KEYS)
-@pytest.mark.parametrize("mode", [MODE_FILTER, MODE_AUTOMATON])
-def test_fixture_counts(gm, fixture_counts, tokens, key, mode):
+@pytest.mark.parametrize("variant", [(MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL)])
+def test_fixture_counts(gm, fixture_counts, tokens, key, variant):
     fx = fixture_counts["fixtures"][key]
     arena = K.HostArena.from_pcap(os.path.join(DATA, fx["pcap"]), fx["mode"])
     assert arena.n_pkts == fx["payloads"] and arena.payload_bytes == fx["payload_bytes"]
-    got = gpu_counts(gm, tokens, arena, mode)
+    got = gpu_counts(gm, tokens, arena, variant[0], kernel=variant[1])
     assert got.tolist() == fx["counts"]
 
 
@@ -190,7 +191,8 @@ def test_uniform_length_few_packets(gm, oracle):
     """Fewer packets than wavefronts, and a run length that does not divide the packet count."""
     for n in (1, 2, 3, 5, 63, 64, 65, 1000, 8193):
         payloads = [(b"xyz%05d-" % k) * 13 for k in range(n)]
-        check_payloads(gm, oracle, payloads, [b"xyz00", b"-xyz", b"z"], variants=((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_GENERAL)))
+        check_payloads(gm, oracle, payloads, [b"xyz00", b"-xyz", b"z"],
+                       variants=((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED), (MODE_FILTER, KERNEL_GENERAL)))
 
 
 def test_high_bit_bytes_and_all_values(gm, oracle):
@@ -250,6 +252,33 @@ def test_empty_inputs(gm, oracle):
     check_payloads(gm, oracle, [b"x"], [b"x", b"xx"])
 
 
+def test_non_packed_arena_takes_the_general_kernel(gm, oracle):
+    """Slots with gaps and in shuffled order: legal for the C-ABI (16-byte aligned, in bounds), not
+    packed, so neither streaming kernel applies."""
+    rng = random.Random(17)
+    payloads = [bytes(rng.choice(b"abc") for _ in range(rng.randrange(0, 700))) for _ in range(500)]
+    order = list(range(len(payloads)))
+    rng.shuffle(order)
+    off = np.zeros(len(payloads), dtype=np.uint64)
+    pos = 0
+    for k in order:
+        pos += 16 * rng.randrange(0, 4)                 # gap
+        off[k] = pos
+        pos += max(16, (len(payloads[k]) + 15) // 16 * 16)
+    arena = np.full(pos + 64, ord("b"), dtype=np.uint8)  # non-zero filler in the gaps
+    for k, p in enumerate(payloads):
+        arena[int(off[k]):int(off[k]) + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    ln = np.array([len(p) for p in payloads], dtype=np.uint32)
+    pats = [b"ab", b"abcab", b"b", b"cabcabcabcab"]
+    want, _ = oracle.count(arena, off, ln, pats)
+    gm.set_patterns(pats)
+    gm.load_arena(arena, off, ln)
+    for kernel in (KERNEL_AUTO, KERNEL_PACKED, KERNEL_GENERAL):
+        gm.set_option(OPT_KERNEL, kernel)
+        assert gm.scan()[0].tolist() == want.tolist()
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+
+
 def test_layout_contract_is_checked(gm):
     gm.set_patterns([b"http"])
     a = np.zeros(256, dtype=np.uint8)
@@ -295,7 +324,7 @@ def test_synth_device_equals_host_and_oracle(gm, oracle):
     gm.set_patterns([needle, b"qz", b"a"])
     gm.attach_arena(d_arena, d_off, d_len)
     want, _ = oracle.count(host, off, ln, [needle, b"qz", b"a"], threads=8)
-    for kernel in (KERNEL_AUTO, KERNEL_GENERAL):
+    for kernel in (KERNEL_AUTO, KERNEL_PACKED, KERNEL_GENERAL):
         gm.set_option(OPT_KERNEL, kernel)
         got, _ = gm.scan()
         assert got.tolist() == want.tolist()
@@ -324,11 +353,16 @@ def test_synth_zipf_with_nuls(gm, oracle):
         gm.set_patterns(pats)
         gm.attach_arena(d_arena, d_off, d_len)
         want, _ = oracle.count(host, off, ln, pats, threads=8)
-        for mode in (MODE_FILTER, MODE_AUTOMATON):
+        for mode, kernel in VARIANTS:
             gm.set_option(OPT_MODE, mode)
-            got, _ = gm.scan()
-            assert got.tolist() == want.tolist()
+            gm.set_option(OPT_KERNEL, kernel)
+            for bpc in (0, 1, 16):
+                gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+                got, _ = gm.scan()
+                assert got.tolist() == want.tolist(), (mode, kernel, bpc)
         gm.set_option(OPT_MODE, MODE_FILTER)
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+        gm.set_option(OPT_BLOCKS_PER_CU, 0)
     gm.set_stream(None)
 
 
@@ -345,7 +379,7 @@ def test_full_size_property_1m(gm):
     gm.set_patterns([needle])
     gm.attach_arena(d_arena, d_off, d_len)
     assert gm.arena_info() == (n, n * 1500)
-    for kernel in (KERNEL_AUTO, KERNEL_GENERAL):
+    for kernel in (KERNEL_AUTO, KERNEL_PACKED, KERNEL_GENERAL):
         for nt in (1, 0):
             for bpc in (8, 3):
                 gm.set_option(OPT_KERNEL, kernel)

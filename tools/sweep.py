@@ -24,7 +24,8 @@ def main():
     ap.add_argument("--bpcs", default="4,6,8")
     ap.add_argument("--nts", default="1,0")
     ap.add_argument("--modes", default="0")
-    ap.add_argument("--kernels", default="0,1", help="0 auto (flat for uniform arenas), 1 general")
+    ap.add_argument("--kernels", default="0,1", help="0 auto (flat for uniform arenas), 1 general, 2 packed")
+    ap.add_argument("--zipf", action="store_true", help="lengths 64..9000, Zipf s=1.1 (BASELINE configs[4])")
     args = ap.parse_args()
     import torch
     import multithreading_string_matching_amd as K
@@ -36,15 +37,29 @@ def main():
     m = GpuMatcher(0)
     m.set_stream(torch.cuda.current_stream().cuda_stream)
     stride = (L + args.align - 1) // args.align * args.align
-    d_arena = torch.zeros(n * stride + 64, dtype=torch.uint8, device="cuda")
-    d_off = torch.empty(n, dtype=torch.int64, device="cuda")
-    d_len = torch.empty(n, dtype=torch.int32, device="cuda")
-    m.fixed_index(d_off, d_len, L, args.align)
+    if args.zipf:
+        rng = np.random.default_rng(4)
+        ranks = np.arange(1, 9000 - 64 + 2)
+        p = 1.0 / ranks ** 1.1
+        p /= p.sum()
+        lens = (64 + rng.choice(len(ranks), size=n, p=p)).astype(np.uint32)
+        off, ln, nbytes = K.arena_layout(lens, 0, n)
+        d_arena = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+        d_len = torch.from_numpy(ln.astype(np.int32)).cuda()
+        planted = K.synth_count_planted(sp, n, 0, lens=lens)
+        payload = int(lens.sum())
+        stride = 0
+    else:
+        d_arena = torch.zeros(n * stride + 64, dtype=torch.uint8, device="cuda")
+        d_off = torch.empty(n, dtype=torch.int64, device="cuda")
+        d_len = torch.empty(n, dtype=torch.int32, device="cuda")
+        m.fixed_index(d_off, d_len, L, args.align)
+        planted = K.synth_count_planted(sp, n, L)
+        payload = n * L
     m.synth_fill(d_arena, d_off, d_len, sp)
     m.set_patterns([needle])
     m.attach_arena(d_arena, d_off, d_len)
-    planted = K.synth_count_planted(sp, n, L)
-    payload = n * L
     variants = list(itertools.product([int(x) for x in args.kernels.split(",")], [int(x) for x in args.modes.split(",")], [int(x) for x in args.depths.split(",")],
                                       [int(x) for x in args.bpcs.split(",")], [int(x) for x in args.nts.split(",")]))
     res = {v: [] for v in variants}
