@@ -72,6 +72,8 @@ def main() -> None:
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank code path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -90,18 +92,30 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    if dev_index >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n = args.packets_per_gpu
     first_id = rank * n                      # every rank scans its own shard of the global stream
     sp = K.SynthParams.make(seed=SEED, needle=NEEDLE, plant_permille=100)
 
-    m = GpuMatcher(local_rank)
-    stream = torch.cuda.current_stream()
+    # Everything runs on one explicit (non-default) torch stream: the scan kernels are enqueued on it
+    # through the C-ABI, and torch.distributed orders its collectives after the CURRENT stream -- so
+    # the all-reduce of step i waits for step i's counts and overlaps step i+1's scan.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    m = GpuMatcher(dev_index)
     m.set_stream(stream.cuda_stream)
     if args.depth:
         m.set_option(OPT_DEPTH, args.depth)

@@ -79,8 +79,10 @@ int  kmpgpu_device_count(void);                        /* >= 0, or KMPGPU_EHIP  
 int  kmpgpu_init(kmpgpu_ctx **ctx, int device);
 void kmpgpu_destroy(kmpgpu_ctx *ctx);
 
-/* Launch on a caller-owned HIP stream (hipStream_t, e.g. torch's current stream); NULL returns
- * to the context's own stream. */
+/* Launch on a caller-owned HIP stream (hipStream_t, e.g. an explicit torch stream); NULL returns
+ * to the context's own (non-blocking) stream.  The legacy default stream has the handle NULL and
+ * therefore cannot be borrowed: create an explicit stream when work must be ordered with the
+ * caller's (bench.py does). */
 int  kmpgpu_set_stream(kmpgpu_ctx *ctx, void *hip_stream);
 int  kmpgpu_set_option(kmpgpu_ctx *ctx, int key, int64_t value);
 
