@@ -126,8 +126,9 @@ int  kmpgpu_sync(kmpgpu_ctx *ctx);
 int  kmpgpu_profile_begin(kmpgpu_ctx *ctx, uint32_t max_launches);
 int  kmpgpu_profile_end(kmpgpu_ctx *ctx, float *ms_out, uint32_t *n);
 
-/* Counts plus the matches themselves, at most cap of them written to out (host memory);
- * *n_found is the total number found (may exceed cap). */
+/* Counts plus the matches themselves: every (packet, start offset, pattern) that counts, at most
+ * cap of them written to out (host memory, unspecified order); *n_found is the total number found
+ * (may exceed cap).  Needs an arena whose slots are back to back, as kmp_arena builds them. */
 int  kmpgpu_scan_offsets(kmpgpu_ctx *ctx, kmpgpu_match *out, uint64_t cap, uint64_t *n_found,
                          uint64_t *counts_out);
 

@@ -10,6 +10,10 @@
  *
  * stdout is byte-compatible with the reference (serial.c:163-169); throughput details go to
  * stderr.  There is no CPU fallback: without a gfx950 device the program fails with exit code 2.
+ *
+ * Extension (the reference prints counts only, serial.c:163-166): with the environment variable
+ * KMPGPU_OFFSETS_FILE=<path> every match is also written to <path> as "payload,offset,pattern"
+ * lines (payload = index among the extracted payloads, pattern = index in the pattern file).
  */
 #include <errno.h>
 #include <stdio.h>
@@ -137,13 +141,33 @@ int main(int argc, char *argv[])
                 die_gpu("kmpgpu_load_arena");
             lo = hi;
         }
+        const char *off_path = getenv("KMPGPU_OFFSETS_FILE");
+        FILE *off_fp = NULL;
+        if (off_path && off_path[0]) {
+            off_fp = fopen(off_path, "w");
+            if (!off_fp) { perror("KMPGPU_OFFSETS_FILE"); exit(1); }
+        }
+        uint64_t shard_lo = 0;
         for (int r = 0; r < shards; r++) {
             kmpgpu_timing t;
+            if (off_fp) {
+                /* counts first (cheap), then exactly as many match records as were counted */
+                if (kmpgpu_scan(ctx[r], part, &t)) die_gpu("kmpgpu_scan");
+                uint64_t total = 0, found = 0;
+                for (uint32_t i = 0; i < pats.n; i++) total += part[i];
+                kmpgpu_match *mm = (kmpgpu_match *)malloc(sizeof *mm * (size_t)(total ? total : 1));
+                if (!mm || kmpgpu_scan_offsets(ctx[r], mm, total, &found, NULL)) die_gpu("kmpgpu_scan_offsets");
+                for (uint64_t i = 0; i < found && i < total; i++)
+                    fprintf(off_fp, "%llu,%u,%u\n", (unsigned long long)(mm[i].packet + shard_lo), mm[i].offset, mm[i].pattern);
+                free(mm);
+            }
+            shard_lo += arena.n_pkts / (uint64_t)shards + (r == 0 ? arena.n_pkts % (uint64_t)shards : 0);
             if (kmpgpu_scan(ctx[r], part, &t)) die_gpu("kmpgpu_scan");
             for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];     /* mpi_dumping.c:202 MPI_SUM */
             if (t.kernel_ms > kernel_ms) kernel_ms = t.kernel_ms;           /* mpi_dumping.c:206 MPI_MAX */
             h2d_ms += t.h2d_ms;
         }
+        if (off_fp) fclose(off_fp);
         for (int r = 0; r < shards; r++) kmpgpu_destroy(ctx[r]);
         free(ctx); free(reb);
     }

@@ -406,11 +406,60 @@ __device__ __forceinline__ void flat_issue(u32x4 &dst, i32x4 rsrc, uint32_t vo, 
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
 }
 
-/* KMP automaton for the flat kernel: lane scans the text from its own first byte; it stops at a
- * 0x00 (serial.c:191) or at the payload end; matches found all start inside the lane's 16 bytes
- * because at most 15 + m bytes are consumed. */
+/* Per-launch constants of one pattern as the streaming kernels use them. */
+struct PatConst {
+    uint32_t m, first, mask;
+    uint32_t pd[4], pm[4];          /* pattern bytes 4..19 and their byte masks (direct confirmation, m <= 20) */
+};
+
+__device__ __forceinline__ PatConst load_pat_const(const kmp_pattern_dev *gp)
+{
+    PatConst pc;
+    pc.m = gp->m; pc.first = gp->first; pc.mask = gp->mask;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t lo = 4u * (uint32_t)(d + 1);
+        pc.pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
+        pc.pm[d] = (pc.m >= lo + 4u) ? 0xFFFFFFFFu : (pc.m <= lo) ? 0u : ((1u << (8u * (pc.m - lo))) - 1u);
+    }
+    return pc;
+}
+
+/* Match-offset emission (kmpgpu_scan_offsets): {packet, offset, pattern} appended to a device
+ * buffer.  The lanes that found a match are compacted with a ballot: one atomic add per wavefront
+ * reserves their slots, each lane's rank inside the ballot (mbcnt) is its slot. */
+struct Emitter {
+    uint4              *out;        /* kmpgpu_match[cap] viewed as 16-byte records */
+    unsigned long long *counter;    /* matches found so far (may exceed cap)       */
+    unsigned long long  cap;
+    uint32_t            pattern;
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void emit_match(bool ok, uint64_t pkt, uint32_t offset, const Emitter &e)
+{
+    if (!EMIT) return;
+    const uint64_t b = ballot64(ok);                 /* among the lanes that are active here */
+    if (b == 0ull) return;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(b);
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0ull;
+    if (lane == leader) base = atomicAdd(e.counter, (unsigned long long)__builtin_popcountll(b));
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, (int)leader);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), (int)leader);
+    if (ok) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + rank;
+        if (slot < e.cap) e.out[slot] = make_uint4((uint32_t)pkt, (uint32_t)(pkt >> 32), offset, e.pattern);
+    }
+}
+
+/* KMP automaton for the streaming kernels: the lane scans the text from its own first byte; it
+ * stops at a 0x00 (serial.c:191) or at the payload end; matches found all start inside the lane's
+ * 16 bytes because at most 15 + m bytes are consumed. */
+template <bool EMIT>
 __device__ __forceinline__ void automaton_flat(uint4 cur, uint4 nxt, bool act, uint32_t p0, uint32_t L, uint32_t m,
-                                               const kmp_pattern_dev &sp, uint32_t &cnt)
+                                               const kmp_pattern_dev &sp, uint32_t &cnt, uint64_t pkt, const Emitter &em)
 {
     uint32_t j = 0u;
     const uint32_t nsteps = 15u + m;
@@ -424,22 +473,97 @@ __device__ __forceinline__ void automaton_flat(uint4 cur, uint4 nxt, bool act, u
             const uint32_t w  = (s & 8u) ? ((s & 4u) ? c3 : c2) : ((s & 4u) ? c1 : c0);
             const uint32_t ch = (w >> (8u * (s & 3u))) & 0xFFu;
             act = act && (ch != 0u) && (t0 + s < L);
-            if (act) kmp_step(ch, j, m, sp.pat, sp.fail, cnt);
+            if (act) {
+                const uint32_t before = cnt;
+                kmp_step(ch, j, m, sp.pat, sp.fail, cnt);
+                emit_match<EMIT>(cnt != before, pkt, t0 + s + 1u - m, em);
+            }
         }
         t0 += 16u;
-        if (__ballot(act) == 0ull) break;
+        if (ballot64(act) == 0ull) break;
         const uint32_t f0 = sgpr(n0), f1 = sgpr(n1), f2 = sgpr(n2), f3 = sgpr(n3);
         c0 = wave_shl1(c0, f0); c1 = wave_shl1(c1, f1); c2 = wave_shl1(c2, f2); c3 = wave_shl1(c3, f3);
         n0 = wave_shl1(n0, 0u); n1 = wave_shl1(n1, 0u); n2 = wave_shl1(n2, 0u); n3 = wave_shl1(n3, 0u);
     }
 }
 
+/* Rare path, part 1: cut a lane's largest valid start index down by the strlen() rule -- no start
+ * behind a 0x00 of the same packet (earlier lanes since the packet's start lane, or an earlier
+ * chunk: dead_in), and none behind the first 0x00 of the lane's own 16 bytes. */
+__device__ __forceinline__ int32_t nul_limit(int32_t maxi, const uint32_t (&w)[5], uint64_t zl, uint64_t st, bool dead_in, uint32_t lane)
+{
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint64_t st_le = st & (below | (1ull << lane));
+    bool nul_before;
+    if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
+    else {
+        const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
+        nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
+    }
+    const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
+    uint32_t zi = 16u;                               /* first 0x00 inside the lane's own 16 bytes (16 = none) */
+    if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
+    if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
+    if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
+    if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
+    return nul_before ? -1 : min(maxi, (int32_t)zi - 1);
+}
+
+/* Rare path, part 2: count (and optionally emit) the matches that start at index <= maxi of each
+ * lane.  Patterns of <= 4 bytes are exact after the filter; 5..20 bytes with few candidate lanes are
+ * compared dword-wise straight from registers (W = the lane's 16 bytes + the next 20 of the stream);
+ * everything else runs the KMP automaton. */
+template <bool MASKED, bool EMIT>
+__device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], uint4 v, u32x4 bn, int32_t maxi, uint32_t p0, uint32_t L,
+                                              const PatConst &pc, const kmp_pattern_dev &sp, uint32_t &cnt, uint64_t pkt,
+                                              const Emitter &em)
+{
+    const uint32_t m = pc.m;
+    const uint64_t ba = ballot64(maxi >= 0);
+    if (m <= 4u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
+                const bool ok = is_cand<MASKED>(d0, pc.first, pc.mask) && (4 * q + a) <= maxi;
+                cnt += ok ? 1u : 0u;
+                emit_match<EMIT>(ok, pkt, p0 + (uint32_t)(4 * q + a), em);
+            }
+        }
+    } else if (ba != 0ull) {
+        if (m <= 20u && __builtin_popcountll(ba) <= 16) {
+            const uint32_t W[10] = {w[0], w[1], w[2], w[3], w[4], wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
+                                    wave_shl1(v.w, sgpr(bn.w)), wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
+                    bool ok = (d0 == pc.first) && (4 * q + a) <= maxi;
+                    if (ballot64(ok) != 0ull) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t t = a ? __builtin_amdgcn_alignbyte(W[q + d + 2], W[q + d + 1], a) : W[q + d + 1];
+                            ok = ok && (((t ^ pc.pd[d]) & pc.pm[d]) == 0u);
+                        }
+                        cnt += ok ? 1u : 0u;
+                        emit_match<EMIT>(ok, pkt, p0 + (uint32_t)(4 * q + a), em);
+                    }
+                }
+            }
+        } else {
+            automaton_flat<EMIT>(v, make_uint4(bn.x, bn.y, bn.z, bn.w), maxi >= 0, p0, L, m, sp, cnt, pkt, em);
+        }
+    }
+}
+
 /* ABL (tuning only): 0 normal, 1 loads + waits only (no matching work), 2 matching work only (ring never refilled). */
-template <int DEPTH, bool MASKED, bool NT, int ABL = 0>
+template <int DEPTH, bool MASKED, bool NT, int ABL = 0, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
                      uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
-                     const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials)
+                     const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
 {
     __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
@@ -450,19 +574,12 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
         reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
     __syncthreads();
 
-    const uint32_t m = gp->m, first = gp->first, mask = gp->mask;
+    const PatConst pc = load_pat_const(gp);
+    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
-    /* pattern bytes 4..19 and their masks, for the direct confirmation of candidates (m <= 20) */
-    uint32_t pd[4], pm[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const uint32_t lo = 4u * (uint32_t)(d + 1);
-        pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
-        pm[d] = (m >= lo + 4u) ? 0xFFFFFFFFu : (m <= lo) ? 0u : ((1u << (8u * (m - lo))) - 1u);
-    }
-
+    if (EMIT) em.pattern = pid;
     /* this wavefront's packets [k0, k1) = bytes [0, range) behind base */
     const uint64_t k0 = gw * pkts_per_wave;
     const uint64_t k1 = min(n_pkts, k0 + pkts_per_wave);
@@ -508,62 +625,9 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                          * window inside the payload, no 0x00 before it, lane has a candidate at all. */
                         int32_t maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
                         if (fm != 0u) maxi = -1;
-                        if (zl != 0ull || dead_in) {
-                            const uint64_t below = (1ull << lane) - 1ull;
-                            const uint64_t st_le = st & (below | (1ull << lane));
-                            bool nul_before;
-                            if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
-                            else {
-                                const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
-                                nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
-                            }
-                            /* index of the first 0x00 inside the lane's own 16 bytes (16 = none) */
-                            const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
-                            uint32_t zi = 16u;
-                            if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
-                            if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
-                            if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
-                            if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
-                            maxi = nul_before ? -1 : min(maxi, (int32_t)zi - 1);
-                        }
-                        const uint64_t ba = ballot64(maxi >= 0);
-                        if (m <= 4u) {
-                            /* the filter compared all m bytes */
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                                for (int a = 0; a < 4; ++a) {
-                                    const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
-                                    cnt += (is_cand<MASKED>(d0, first, mask) && (4 * q + a) <= maxi) ? 1u : 0u;
-                                }
-                            }
-                        } else if (ba != 0ull) {
-                            if (m <= 20u && __builtin_popcountll(ba) <= 16) {
-                                /* few candidates: compare the rest of the pattern dword-wise, straight from
-                                 * registers.  W[0..8] = the lane's 16 bytes + the next 20 of the stream. */
-                                const uint32_t W[10] = {w[0], w[1], w[2], w[3], w[4], wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
-                                                        wave_shl1(v.w, sgpr(bn.w)),
-                                                        wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                                    for (int a = 0; a < 4; ++a) {
-                                        const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
-                                        bool ok = (d0 == first) && (4 * q + a) <= maxi;
-                                        if (ballot64(ok) != 0ull) {
-#pragma unroll
-                                            for (int d = 0; d < 4; ++d) {
-                                                const uint32_t t = a ? __builtin_amdgcn_alignbyte(W[q + d + 2], W[q + d + 1], a) : W[q + d + 1];
-                                                ok = ok && (((t ^ pd[d]) & pm[d]) == 0u);
-                                            }
-                                            cnt += ok ? 1u : 0u;
-                                        }
-                                    }
-                                }
-                            } else {
-                                automaton_flat(v, make_uint4(bn.x, bn.y, bn.z, bn.w), maxi >= 0, p0, L, m, s_pat, cnt);
-                            }
-                        }
+                        if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                        const uint64_t pkt = EMIT ? (k0 + (uint64_t)((cb + vo0 - p0) / stride)) : 0ull;
+                        confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, pkt, em);
                     }
                     /* this lane's position inside its packet, one chunk further */
                     p0 += step_mod;
@@ -634,12 +698,12 @@ kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict
     plan[w].off = (lo < n) ? pkt_off[lo] : end;
 }
 
-template <int DEPTH, bool MASKED, bool NT>
+template <int DEPTH, bool MASKED, bool NT, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
                        const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,
                        const kmp_plan_entry *__restrict__ plan, const kmp_pattern_dev *__restrict__ patterns,
-                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials)
+                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
 {
     __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
@@ -650,18 +714,12 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
         reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
     __syncthreads();
 
-    const uint32_t m = gp->m, first = gp->first, mask = gp->mask;
+    const PatConst pc = load_pat_const(gp);
+    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
-    uint32_t pd[4], pm[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const uint32_t lo = 4u * (uint32_t)(d + 1);
-        pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
-        pm[d] = (m >= lo + 4u) ? 0xFFFFFFFFu : (m <= lo) ? 0u : ((1u << (8u * (m - lo))) - 1u);
-    }
-
+    if (EMIT) em.pattern = pid;
     const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
     const uint64_t off0 = plan[gw].off;
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;    /* planner guarantees < 2^31 */
@@ -712,66 +770,17 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                         /* rare path: which packet does a candidate lane sit in? */
                         int32_t  maxi = -1;
                         uint32_t p0 = 0u, L = 0u;
+                        uint64_t kl = 0ull;
                         if (fm == 0u) {
                             const uint64_t le = (2ull << lane) - 1ull;                  /* lanes <= own (lane 63: all ones) */
-                            const uint64_t kl = kbase + (uint64_t)__builtin_popcountll(st & le);
+                            kl = kbase + (uint64_t)__builtin_popcountll(st & le);
                             const uint64_t po = pkt_off[kl];
                             L  = pkt_len[kl];
                             p0 = (uint32_t)(off0 + cb + vo0 - po);
                             maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
                         }
-                        if (zl != 0ull || dead_in) {
-                            const uint64_t below = (1ull << lane) - 1ull;
-                            const uint64_t st_le = st & (below | (1ull << lane));
-                            bool nul_before;
-                            if (st_le == 0ull) nul_before = dead_in || ((zl & below) != 0ull);
-                            else {
-                                const uint32_t sl = 63u - (uint32_t)__builtin_clzll(st_le);
-                                nul_before = (zl & below & ~((1ull << sl) - 1ull)) != 0ull;
-                            }
-                            const uint32_t m0 = zero_byte_mask(w[0]), m1 = zero_byte_mask(w[1]), m2 = zero_byte_mask(w[2]), m3 = zero_byte_mask(w[3]);
-                            uint32_t zi = 16u;
-                            if (m3) zi = 12u + ((uint32_t)__builtin_ctz(m3) >> 3);
-                            if (m2) zi = 8u + ((uint32_t)__builtin_ctz(m2) >> 3);
-                            if (m1) zi = 4u + ((uint32_t)__builtin_ctz(m1) >> 3);
-                            if (m0) zi = (uint32_t)__builtin_ctz(m0) >> 3;
-                            maxi = nul_before ? -1 : min(maxi, (int32_t)zi - 1);
-                        }
-                        const uint64_t ba = ballot64(maxi >= 0);
-                        if (m <= 4u) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                                for (int a = 0; a < 4; ++a) {
-                                    const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
-                                    cnt += (is_cand<MASKED>(d0, first, mask) && (4 * q + a) <= maxi) ? 1u : 0u;
-                                }
-                            }
-                        } else if (ba != 0ull) {
-                            if (m <= 20u && __builtin_popcountll(ba) <= 16) {
-                                const uint32_t W[10] = {w[0], w[1], w[2], w[3], w[4], wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
-                                                        wave_shl1(v.w, sgpr(bn.w)),
-                                                        wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                                    for (int a = 0; a < 4; ++a) {
-                                        const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
-                                        bool ok = (d0 == first) && (4 * q + a) <= maxi;
-                                        if (ballot64(ok) != 0ull) {
-#pragma unroll
-                                            for (int d = 0; d < 4; ++d) {
-                                                const uint32_t t = a ? __builtin_amdgcn_alignbyte(W[q + d + 2], W[q + d + 1], a) : W[q + d + 1];
-                                                ok = ok && (((t ^ pd[d]) & pm[d]) == 0u);
-                                            }
-                                            cnt += ok ? 1u : 0u;
-                                        }
-                                    }
-                                }
-                            } else {
-                                automaton_flat(v, make_uint4(bn.x, bn.y, bn.z, bn.w), maxi >= 0, p0, L, m, s_pat, cnt);
-                            }
-                        }
+                        if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                        confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, kl, em);
                     }
                     kbase += (uint64_t)__builtin_popcountll(st);
                 }
@@ -929,22 +938,33 @@ hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st)
 }
 
 namespace {
+Emitter emitter_of(const kmp_scan_args &a)
+{
+    Emitter e;
+    e.out = reinterpret_cast<uint4 *>(a.emit_out);
+    e.counter = a.emit_counter;
+    e.cap = a.emit_cap;
+    e.pattern = 0;
+    return e;
+}
+
 template <int DEPTH, bool MASKED>
 hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
 {
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
-    if (a.ablate == 1 && DEPTH == 4 && !MASKED)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 1>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
-                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+    const Emitter em = emitter_of(a);
+#define KMP_FLAT_ARGS a.arena, a.n_pkts, a.uniform_stride, a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials, em
+    if (a.emit_out)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, MASKED, true, 0, true>), grid, block, 0, st, KMP_FLAT_ARGS);
+    else if (a.ablate == 1 && DEPTH == 4 && !MASKED)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 1>), grid, block, 0, st, KMP_FLAT_ARGS);
     else if (a.ablate == 2 && DEPTH == 4 && !MASKED)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 2>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
-                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 2>), grid, block, 0, st, KMP_FLAT_ARGS);
     else if (a.nontemporal)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
-                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_FLAT_ARGS);
     else
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, false>), grid, block, 0, st, a.arena, a.n_pkts, a.uniform_stride,
-                           a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, false>), grid, block, 0, st, KMP_FLAT_ARGS);
+#undef KMP_FLAT_ARGS
     return hipGetLastError();
 }
 template <bool MASKED>
@@ -967,12 +987,15 @@ hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
 {
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
-    if (a.nontemporal)
-        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, true>), grid, block, 0, st, a.arena, a.pkt_off, a.pkt_len, a.bitmap,
-                           plan, a.patterns, a.pat_ids, a.partials);
+    const Emitter em = emitter_of(a);
+#define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, em
+    if (a.emit_out)
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_PACKED_ARGS);
+    else if (a.nontemporal)
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_PACKED_ARGS);
     else
-        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, false>), grid, block, 0, st, a.arena, a.pkt_off, a.pkt_len, a.bitmap,
-                           plan, a.patterns, a.pat_ids, a.partials);
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, false>), grid, block, 0, st, KMP_PACKED_ARGS);
+#undef KMP_PACKED_ARGS
     return hipGetLastError();
 }
 }  // namespace

@@ -28,6 +28,10 @@ struct kmp_scan_args {
     /* packed kernel only */
     const unsigned long long *bitmap;   /* one bit per 16-byte slot of the arena: a payload starts here */
     const void            *plan;         /* kmp_plan_entry[waves + 1]                                   */
+    /* match-offset emission (streaming kernels only): kmpgpu_match[emit_cap], running counter */
+    void                  *emit_out;
+    unsigned long long    *emit_counter;
+    unsigned long long     emit_cap;
     int                    ablate;       /* tuning only: 1 memory-only, 2 compute-only variants of the flat kernel */
 };
 

@@ -154,7 +154,9 @@ int prepare_packed(kmpgpu_ctx *c)
 }
 
 /* Enqueue one full pass: scan launches (patterns grouped by "shorter than 4 bytes") + reduce. */
-int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
+struct EmitTarget { void *out = nullptr; unsigned long long *counter = nullptr; unsigned long long cap = 0; };
+
+int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, const EmitTarget *emit = nullptr)
 {
     if (!d_out) d_out = c->d_counts;
     if (!c->d_patterns || c->n_pat == 0) return fail(KMPGPU_ESTATE, "kmpgpu_scan: no patterns set");
@@ -174,6 +176,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
     a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; a.mode = c->mode;
     a.nontemporal = c->nontemporal != 0;
     a.ablate = c->ablate;
+    if (emit) { a.emit_out = emit->out; a.emit_counter = emit->counter; a.emit_cap = emit->cap; }
     /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
     const uint64_t nwaves = (uint64_t)bx * KMP_BLOCK_WAVES;
     const uint64_t ppw = (c->n_pkts + nwaves - 1) / nwaves;
@@ -217,6 +220,8 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out)
                 e0 = c->prof_ev[2 * c->prof_n]; e1 = c->prof_ev[2 * c->prof_n + 1];
                 HIP_TRY(hipEventRecord(e0, c->stream));
             }
+            if (emit && !flat && !packed)
+                return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets needs an arena whose slots are back to back (as kmp_arena builds them)");
             HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream));
@@ -545,9 +550,42 @@ int kmpgpu_profile_end(kmpgpu_ctx *c, float *ms_out, uint32_t *n)
 
 int kmpgpu_scan_offsets(kmpgpu_ctx *c, kmpgpu_match *out, uint64_t cap, uint64_t *n_found, uint64_t *counts_out)
 {
-    (void)out; (void)cap; (void)n_found; (void)counts_out;
-    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: ctx is NULL");
-    return fail(KMPGPU_ESTATE, "kmpgpu_scan_offsets: not built yet");
+    if (!c || !n_found) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: NULL argument");
+    if (cap && !out) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: out is NULL");
+    if (c->mode != 0 || c->kernel_sel == 1) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets runs on the streaming kernels only (mode 0, kernel 0 or 2)");
+    static_assert(sizeof(kmpgpu_match) == 16, "kmpgpu_match is a 16-byte record");
+    HIP_TRY(hipSetDevice(c->device));
+    *n_found = 0;
+    void *d_out = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (cap ? cap : 1) * sizeof(kmpgpu_match)));
+    hipError_t e = hipMalloc(&d_cnt, sizeof(unsigned long long));
+    int rc = KMPGPU_OK;
+    unsigned long long found = 0;
+    if (e != hipSuccess) rc = fail(KMPGPU_EHIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    if (!rc && (e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream)) != hipSuccess)
+        rc = fail(KMPGPU_EHIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    if (!rc) {
+        EmitTarget t;
+        t.out = d_out; t.counter = d_cnt; t.cap = cap;
+        rc = enqueue_pass(c, nullptr, nullptr, &t);
+    }
+    if (!rc && (e = hipMemcpyAsync(&found, d_cnt, sizeof found, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        rc = fail(KMPGPU_EHIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    if (!rc && c->n_pat && counts_out &&
+        (e = hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint64_t) * c->n_pat, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        rc = fail(KMPGPU_EHIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    if (!rc && (e = hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail(KMPGPU_EHIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    if (!rc) {
+        const unsigned long long n = found < cap ? found : cap;
+        if (n && (e = hipMemcpy(out, d_out, n * sizeof(kmpgpu_match), hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = fail(KMPGPU_EHIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+        if (counts_out && c->n_pat) memcpy(counts_out, c->h_counts, sizeof(uint64_t) * c->n_pat);
+        *n_found = found;
+    }
+    (void)hipFree(d_out);
+    if (d_cnt) (void)hipFree(d_cnt);
+    return rc;
 }
 
 int kmpgpu_synth_fill(kmpgpu_ctx *c, void *d_arena, const void *d_pkt_off, const void *d_pkt_len, uint64_t first_pkt_id,

@@ -252,6 +252,70 @@ def test_empty_inputs(gm, oracle):
     check_payloads(gm, oracle, [b"x"], [b"x", b"xx"])
 
 
+# ------------------------------------------------------------------------------------------------
+# match offsets (north_star: "per-pattern match counts/offsets out")
+# ------------------------------------------------------------------------------------------------
+def _expected_matches(payloads, patterns):
+    out = []
+    for k, text in enumerate(payloads):
+        E = text.index(0) if 0 in text else len(text)
+        for i, p in enumerate(patterns):
+            s = text.find(p, 0, E)
+            while s != -1:
+                out.append((k, s, i))
+                s = text.find(p, s + 1, E)
+    return sorted(out)
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+def test_scan_offsets(gm, oracle, uniform):
+    rng = random.Random(23 + uniform)
+    pats = [b"ab", b"abc", b"abcab", b"b", b"abcabcabcabcabcab", b"c" * 25]
+    payloads = []
+    for k in range(400):
+        L = 1500 if uniform else rng.randrange(0, 3000)
+        b = bytearray(rng.choice(b"abc") for _ in range(L))
+        if L and rng.random() < 0.3:
+            b[rng.randrange(L)] = 0
+        if L > 100 and rng.random() < 0.2:
+            s0 = rng.randrange(0, L - 40)
+            b[s0:s0 + 30] = b"c" * 30
+        payloads.append(bytes(b))
+    want = _expected_matches(payloads, pats)
+    arena = K.HostArena.from_payloads(payloads)
+    counts_want, _ = oracle.count(arena.bytes, arena.off, arena.len, pats)
+    assert len(want) == int(counts_want.sum())
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    gm.load_arena(arena)
+    for kernel in (KERNEL_AUTO, KERNEL_PACKED):
+        gm.set_option(OPT_KERNEL, kernel)
+        got, found, counts = gm.scan_offsets(len(want) + 10)
+        assert found == len(want) and counts.tolist() == counts_want.tolist()
+        assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in got) == want
+    # a buffer that is too small: the total is still reported, the buffer holds valid matches
+    got, found, counts = gm.scan_offsets(100)
+    assert found == len(want) and len(got) == 100
+    assert set((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in got) <= set(want)
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+
+
+def test_scan_offsets_fixture(gm, tokens, fixture_counts):
+    arena = K.HostArena.from_pcap(os.path.join(DATA, "udp_1000.pcap"), "udp")
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+    gm.set_patterns(tokens)
+    gm.load_arena(arena)
+    got, found, counts = gm.scan_offsets(4096)
+    assert counts.tolist() == fixture_counts["fixtures"]["udp_1000.pcap:udp"]["counts"] and found == int(counts.sum()) == len(got)
+    for r in got:                                   # every reported offset really is a match inside text[0:E)
+        text = arena.payload(int(r["packet"]))
+        p = tokens[int(r["pattern"])]
+        s0 = int(r["offset"])
+        E = text.index(0) if 0 in text else len(text)
+        assert text[s0:s0 + len(p)] == p and s0 + len(p) <= E
+
+
 def test_non_packed_arena_takes_the_general_kernel(gm, oracle):
     """Slots with gaps and in shuffled order: legal for the C-ABI (16-byte aligned, in bounds), not
     packed, so neither streaming kernel applies."""
@@ -437,6 +501,26 @@ def test_cli_openmp_data_form(fixture_counts, tokens, shards):
     assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
     r = _run("openmp_data", os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), shards)
     assert r.returncode == 0 and _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
+def test_cli_offsets_file(tokens, fixture_counts, tmp_path):
+    out = tmp_path / "offsets.csv"
+    exe = os.path.join(_lib.BINDIR, "openmp_data")
+    env = dict(os.environ, KMPGPU_OFFSETS_FILE=str(out))
+    r = subprocess.run([exe, os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), "3"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
+    assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+    arena = K.HostArena.from_pcap(os.path.join(DATA, "big_udp.pcap"), "udp")
+    rows = [tuple(map(int, line.split(","))) for line in out.read_text().splitlines()]
+    assert len(rows) == sum(fx["counts"]) and len(set(rows)) == len(rows)
+    per_pat = [0] * len(tokens)
+    for pkt, off, pat in rows:
+        text = arena.payload(pkt)
+        assert text[off:off + len(tokens[pat])] == tokens[pat]
+        per_pat[pat] += 1
+    assert per_pat == fx["counts"]
 
 
 def test_cli_pcap_route_equals_arena_route(gm, tmp_path):
