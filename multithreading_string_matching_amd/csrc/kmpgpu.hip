@@ -109,10 +109,17 @@ bool use_packed(const kmpgpu_ctx *c)
 
 uint32_t grid_blocks(const kmpgpu_ctx *c)
 {
-    /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat streaming kernel (it is
-     * HBM-bound from 2 blocks/CU on) and 8 for the general kernel */
-    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : ((use_flat(c) || use_packed(c)) ? 4 : 8);
+    /* persistent grid: measured best on MI355X is 4 blocks/CU for the streaming kernels (HBM-bound
+     * from 2 blocks/CU on) and 8 for the general kernel */
+    const bool streaming = use_flat(c) || use_packed(c);
+    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : (streaming ? 4 : 8);
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
+    if (streaming && c->blocks_per_cu <= 0) {
+        /* small captures: give every wavefront at least 8 KiB to stream instead of launching
+         * thousands of nearly empty wavefronts per pattern */
+        const uint64_t span = c->span_end - c->uni_off0;
+        need = std::min<uint64_t>(need, (span + KMP_BLOCK_WAVES * 8192ull - 1) / (KMP_BLOCK_WAVES * 8192ull));
+    }
     uint64_t cap = (uint64_t)c->cu_count * (uint64_t)bpc;
     uint64_t b = std::min(need, cap);
     return (uint32_t)std::max<uint64_t>(b, 1);
