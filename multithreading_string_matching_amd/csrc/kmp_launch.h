@@ -42,7 +42,9 @@ hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned
 hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
                            void *plan, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
-                             uint32_t n_ids, unsigned long long *counts, hipStream_t st);
+                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr);
+hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
+                                 hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,
                                uint32_t *err, unsigned long long *payload_bytes, hipStream_t st);
 hipError_t kmp_launch_synth_fill(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t first_pkt_id,

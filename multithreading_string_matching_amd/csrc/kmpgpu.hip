@@ -63,6 +63,13 @@ struct kmpgpu_ctx {
     kmp_pattern_dev      *d_patterns = nullptr;
     uint32_t             *d_ids = nullptr;          /* [n_pat]: long patterns (m >= 4) first, then short */
     uint32_t              n_long = 0, n_short = 0;
+    /* fused multi-pattern pass: unique patterns of 2..20 bytes share one arena read */
+    uint32_t             *d_multi_tables = nullptr;  /* layout: kmp_device.h KMP_MULTI_* */
+    uint32_t              multi_words = 0, n_multi_unique = 0, n_multi = 0;
+    uint32_t             *d_multi_ids = nullptr;     /* [n_multi] pattern indices counted by the fused pass   */
+    uint32_t             *d_multi_rows = nullptr;    /* [n_multi] their unique-pattern row                     */
+    uint32_t             *d_rest_ids = nullptr;      /* [rest_long + rest_short] everything else, long first  */
+    uint32_t              rest_long = 0, rest_short = 0;
 
     /* arena */
     const uint8_t  *d_arena = nullptr;
@@ -89,7 +96,7 @@ struct kmpgpu_ctx {
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, ablate = 0;
+    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, ablate = 0, fused = 2 /* auto */;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -102,6 +109,15 @@ struct kmpgpu_ctx {
 namespace {
 
 bool use_flat(const kmpgpu_ctx *c) { return c->uniform && c->kernel_sel == 0 && c->mode == 0; }
+/* Fused multi-pattern pass: explicit (1) or automatic (2: from 5 unique eligible patterns on, where it
+ * beats one streaming pass per pattern -- profiles/r01_multipattern.txt). */
+bool use_fused(const kmpgpu_ctx *c)
+{
+    if (!c->packed || !c->d_bitmap || c->mode != 0 || c->kernel_sel == 1 || !c->d_multi_tables) return false;
+    if (c->fused == 1) return c->n_multi_unique >= 2;
+    return c->fused == 2 && c->n_multi_unique >= 5;
+}
+
 bool use_packed(const kmpgpu_ctx *c)
 {
     return c->packed && c->d_bitmap && c->mode == 0 && (c->kernel_sel == 2 || (c->kernel_sel == 0 && !c->uniform));
@@ -118,7 +134,8 @@ uint32_t grid_blocks(const kmpgpu_ctx *c)
         /* small captures: give every wavefront at least 8 KiB to stream instead of launching
          * thousands of nearly empty wavefronts per pattern */
         const uint64_t span = c->span_end - c->uni_off0;
-        need = std::min<uint64_t>(need, (span + KMP_BLOCK_WAVES * 8192ull - 1) / (KMP_BLOCK_WAVES * 8192ull));
+        const uint64_t per_wave = use_fused(c) ? 2048ull : 8192ull;      /* the fused pass does ~10x the work per byte */
+        need = std::min<uint64_t>(need, (span + KMP_BLOCK_WAVES * per_wave - 1) / (KMP_BLOCK_WAVES * per_wave));
     }
     uint64_t cap = (uint64_t)c->cu_count * (uint64_t)bpc;
     uint64_t b = std::min(need, cap);
@@ -192,9 +209,11 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         a.arena = c->d_arena + c->uni_off0;
         a.uniform_stride = c->uni_stride; a.uniform_len = c->uni_len; a.pkts_per_wave = (uint32_t)ppw;
     }
-    /* packed arenas of mixed lengths: byte-balanced wavefront ranges (plan) + packet-start bitmap */
+    /* packed arenas: byte-balanced wavefront ranges (plan) + packet-start bitmap, used by the packed
+     * streaming kernel (mixed lengths) and by the fused multi-pattern pass */
+    const bool fused = !emit && use_fused(c);
     bool packed = !flat && use_packed(c);
-    if (packed) {
+    if (packed || fused) {
         const uint64_t span = c->span_end - c->uni_off0;
         const uint64_t bpw = (((span + nwaves - 1) / nwaves) + 15ull) & ~15ull;
         if (bpw >= (1ull << 30)) packed = false;
@@ -212,21 +231,46 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             a.bitmap = c->d_bitmap; a.plan = c->d_plan;
         }
     }
+    const bool do_fused = fused && a.plan != nullptr;
 
-    struct Group { uint32_t first, n; bool masked; } groups[2] = {{0, c->n_long, false}, {c->n_long, c->n_short, true}};
+    auto record = [&](hipEvent_t &e0, hipEvent_t &e1) -> hipError_t {
+        e0 = e1 = nullptr;
+        if (c->profiling && c->prof_n < c->prof_cap) {
+            e0 = c->prof_ev[2 * c->prof_n]; e1 = c->prof_ev[2 * c->prof_n + 1];
+            return hipEventRecord(e0, c->stream);
+        }
+        return hipSuccess;
+    };
+
+    const uint32_t *ids = c->d_ids;
+    uint32_t n_long = c->n_long, n_short = c->n_short;
+    size_t part_base = 0;                         /* partial rows already used */
+    if (do_fused) {
+        /* one read of the arena for every unique pattern of 2..20 bytes */
+        kmp_scan_args f = a;
+        f.arena = c->d_arena;
+        f.partials = c->d_partials;
+        hipEvent_t e0, e1;
+        HIP_TRY(record(e0, e1));
+        HIP_TRY(kmp_launch_scan_multi(f, c->d_multi_tables, c->multi_words, c->n_multi_unique, c->stream));
+        if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
+        HIP_TRY(kmp_launch_reduce(c->d_partials, bx, c->d_multi_ids, c->n_multi, d_out, c->stream, c->d_multi_rows));
+        ++nl;
+        part_base = c->n_multi_unique;
+        ids = c->d_rest_ids; n_long = c->rest_long; n_short = c->rest_short;
+    }
+
+    struct Group { uint32_t first, n; bool masked; } groups[2] = {{0, n_long, false}, {n_long, n_short, true}};
     for (const Group &g : groups) {
         /* gridDim.y is limited to 65535 */
         for (uint32_t done = 0; done < g.n; done += 65535u) {
             const uint32_t n = std::min(65535u, g.n - done);
-            a.pat_ids = c->d_ids + g.first + done;
+            a.pat_ids = ids + g.first + done;
             a.n_ids = n;
-            a.partials = c->d_partials + (size_t)(g.first + done) * bx;
+            a.partials = c->d_partials + (part_base + g.first + done) * bx;
             a.masked = g.masked;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c->profiling && c->prof_n < c->prof_cap) {
-                e0 = c->prof_ev[2 * c->prof_n]; e1 = c->prof_ev[2 * c->prof_n + 1];
-                HIP_TRY(hipEventRecord(e0, c->stream));
-            }
+            hipEvent_t e0, e1;
+            HIP_TRY(record(e0, e1));
             if (emit && !flat && !packed)
                 return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets needs an arena whose slots are back to back (as kmp_arena builds them)");
             HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
@@ -296,6 +340,10 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_plan) (void)hipFree(c->d_plan);
+    if (c->d_multi_tables) (void)hipFree(c->d_multi_tables);
+    if (c->d_multi_ids) (void)hipFree(c->d_multi_ids);
+    if (c->d_multi_rows) (void)hipFree(c->d_multi_rows);
+    if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -326,7 +374,8 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
         if (value < 2 || value > 8 || value == 7) return fail(KMPGPU_EINVAL, "depth must be 2..6 or 8");
         c->depth = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_FUSED:
-        return KMPGPU_OK;       /* reserved: fused multi-pattern pass */
+        if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "fused must be 0, 1 or 2");
+        c->fused = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_KERNEL:
         if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "kernel selection must be 0, 1 or 2");
         c->kernel_sel = (int)value; return KMPGPU_OK;
@@ -393,6 +442,63 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         c->h_counts = nullptr; c->h_counts_cap = 0;
         HIP_TRY(hipHostMalloc((void **)&c->h_counts, np * sizeof(uint64_t), hipHostMallocDefault));
         c->h_counts_cap = np;
+    }
+
+    /* ---- tables of the fused multi-pattern pass (layout: kmp_device.h) ------------------------- */
+    for (uint32_t **p : {&c->d_multi_tables, &c->d_multi_ids, &c->d_multi_rows, &c->d_rest_ids})
+        if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
+    c->n_multi_unique = c->n_multi = c->multi_words = c->rest_long = c->rest_short = 0;
+    std::vector<std::string> uniq;
+    std::vector<uint32_t> multi_ids, multi_rows, rest_l, rest_s;
+    for (uint32_t i = 0; i < n_pat; i++) {
+        const uint32_t m = pat_len[i];
+        const std::string key((const char *)pat[i], m);
+        uint32_t uid = UINT32_MAX;
+        if (m >= KMP_MULTI_MIN_LEN && m <= KMP_MULTI_MAX_LEN) {
+            auto it = std::find(uniq.begin(), uniq.end(), key);
+            if (it != uniq.end()) uid = (uint32_t)(it - uniq.begin());
+            else if (uniq.size() < KMP_MULTI_MAX_UNIQUE) { uid = (uint32_t)uniq.size(); uniq.push_back(key); }
+        }
+        if (uid != UINT32_MAX) { multi_ids.push_back(i); multi_rows.push_back(uid); }
+        else (m >= 4 ? rest_l : rest_s).push_back(i);
+    }
+    if (uniq.size() >= 2) {
+        const uint32_t U = (uint32_t)uniq.size();
+        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)U * KMP_MULTI_REC_WORDS, 0u);
+        uint16_t *bucket = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_BUCKET_W0);
+        uint16_t *entry = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_ENTRY_W0);
+        std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
+        for (uint32_t u = 0; u < U; u++) {
+            const std::string &p = uniq[u];
+            const uint32_t w16 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8);
+            tab[w16 >> 5] |= 1u << (w16 & 31u);
+            lists[KMP_MULTI_HASH(w16)].push_back(u);
+            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)u * KMP_MULTI_REC_WORDS;
+            for (uint32_t b = 0; b < p.size(); b++) {
+                rec[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
+                rec[5 + (b >> 2)] |= 0xFFu << (8 * (b & 3));
+            }
+            rec[10] = (uint32_t)p.size();
+        }
+        uint32_t pos = 0;
+        for (uint32_t h = 0; h < KMP_MULTI_BUCKETS; h++) {
+            if (lists[h].empty()) { bucket[h] = 0xFFFFu; continue; }
+            bucket[h] = (uint16_t)pos;
+            for (size_t q = 0; q < lists[h].size(); q++)
+                entry[pos++] = (uint16_t)(lists[h][q] | (q + 1 == lists[h].size() ? 0x8000u : 0u));
+        }
+        std::vector<uint32_t> rest(rest_l);
+        rest.insert(rest.end(), rest_s.begin(), rest_s.end());
+        HIP_TRY(hipMalloc(&c->d_multi_tables, tab.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_multi_ids, multi_ids.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_multi_rows, multi_rows.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_rest_ids, (rest.size() ? rest.size() : 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->d_multi_tables, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_multi_ids, multi_ids.data(), multi_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_multi_rows, multi_rows.data(), multi_rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!rest.empty()) HIP_TRY(hipMemcpy(c->d_rest_ids, rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->multi_words = (uint32_t)tab.size(); c->n_multi_unique = U; c->n_multi = (uint32_t)multi_ids.size();
+        c->rest_long = (uint32_t)rest_l.size(); c->rest_short = (uint32_t)rest_s.size();
     }
     return KMPGPU_OK;
 }

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 import multithreading_string_matching_amd as K  # noqa: E402
 from multithreading_string_matching_amd import _lib  # noqa: E402
 from multithreading_string_matching_amd.matcher import (  # noqa: E402
-    KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_KERNEL, OPT_MODE,
+    KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_MODE,
     OPT_NONTEMPORAL, GpuMatcher)
 
 FIXTURE_KEYS = [
@@ -33,21 +33,27 @@ def gm():
     m.close()
 
 
+KERNEL_FUSED = 100          # test-only alias: auto kernel selection + the fused multi-pattern pass
+
+
 def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=4, kernel=KERNEL_AUTO):
     gm.set_option(OPT_MODE, mode)
     gm.set_option(OPT_DEPTH, depth)
-    gm.set_option(OPT_KERNEL, kernel)
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
+    gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
     gm.set_patterns(patterns)
     gm.load_arena(arena)
     out = gm.scan()[0]
     gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+    gm.set_option(OPT_FUSED, 2)
     return out
 
 
 # (mode, kernel): filter+confirm on the auto-selected kernel (flat streaming for uniform-length
 # arenas, packed streaming for mixed lengths), the packed streaming kernel forced, the general
 # one-packet-per-wavefront kernel forced, and the pure KMP automaton.
-VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL))
+VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED), (MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_GENERAL),
+            (MODE_AUTOMATON, KERNEL_GENERAL))
 
 
 def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=4):
@@ -63,7 +69,7 @@ def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=4):
 # golden fixtures
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("key", FIXTURE_KEYS)
-@pytest.mark.parametrize("variant", [(MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL)])
+@pytest.mark.parametrize("variant", [(MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_GENERAL), (MODE_AUTOMATON, KERNEL_GENERAL)])
 def test_fixture_counts(gm, fixture_counts, tokens, key, variant):
     fx = fixture_counts["fixtures"][key]
     arena = K.HostArena.from_pcap(os.path.join(DATA, fx["pcap"]), fx["mode"])
@@ -252,6 +258,28 @@ def test_empty_inputs(gm, oracle):
     check_payloads(gm, oracle, [b"x"], [b"x", b"xx"])
 
 
+def test_fused_multi_pattern_edge_cases(gm, oracle):
+    """The fused pass: duplicates, prefixes of each other, shared 2-byte prefixes (one bucket),
+    1-byte and > 20-byte patterns that fall back to the per-pattern kernels, 256+ unique patterns."""
+    rng = random.Random(31)
+    pats = [b"ab", b"abc", b"abca", b"abcab", b"ab", b"abcabcabcabcabcabcab", b"abcabcabcabcabcabcabc", b"a", b"ba", b"bab", b"cc",
+            b"ccc", b"cccc", b"c" * 20, b"c" * 21, b"bca" * 30, b"abc", b"ca"]
+    payloads = []
+    for k in range(600):
+        L = rng.choice([0, 1, 2, 3, 19, 20, 21, 64, 500, 1024, 1500, 3000])
+        b = bytearray(rng.choice(b"abc") for _ in range(L))
+        if L and rng.random() < 0.35:
+            b[rng.randrange(L)] = 0
+        if L > 200 and rng.random() < 0.3:
+            s0 = rng.randrange(0, L - 100)
+            b[s0:s0 + 90] = b"c" * 90
+        payloads.append(bytes(b))
+    check_payloads(gm, oracle, payloads, pats, variants=((MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_AUTO)))
+    check_payloads(gm, oracle, [p[:1500].ljust(1500, b"a") for p in payloads], pats, variants=((MODE_FILTER, KERNEL_FUSED),))
+    many = [bytes([97 + (i % 3), 97 + (i // 3) % 3, 97 + (i // 9) % 3, 97 + (i // 27) % 3, 97 + (i // 81) % 3, 97 + (i // 243) % 3]) for i in range(300)]
+    check_payloads(gm, oracle, payloads[:200], many, variants=((MODE_FILTER, KERNEL_FUSED),))
+
+
 # ------------------------------------------------------------------------------------------------
 # match offsets (north_star: "per-pattern match counts/offsets out")
 # ------------------------------------------------------------------------------------------------
@@ -419,13 +447,15 @@ def test_synth_zipf_with_nuls(gm, oracle):
         want, _ = oracle.count(host, off, ln, pats, threads=8)
         for mode, kernel in VARIANTS:
             gm.set_option(OPT_MODE, mode)
-            gm.set_option(OPT_KERNEL, kernel)
+            gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
+            gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
             for bpc in (0, 1, 16):
                 gm.set_option(OPT_BLOCKS_PER_CU, bpc)
                 got, _ = gm.scan()
                 assert got.tolist() == want.tolist(), (mode, kernel, bpc)
         gm.set_option(OPT_MODE, MODE_FILTER)
         gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+        gm.set_option(OPT_FUSED, 2)
         gm.set_option(OPT_BLOCKS_PER_CU, 0)
     gm.set_stream(None)
 
