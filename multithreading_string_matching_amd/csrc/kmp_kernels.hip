@@ -830,8 +830,9 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,
                       unsigned long long *__restrict__ partials)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];    /* tables, then n_unique counters */
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];    /* tables, counters, then one chunk window per wavefront */
     uint32_t *s_cnt = s_tab + table_words;
+    uint32_t *s_win = s_tab + ((table_words + n_unique + 3u) & ~3u);
     for (uint32_t i = threadIdx.x; i < table_words; i += KMP_BLOCK_THREADS) s_tab[i] = tables[i];
     for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
     __syncthreads();
@@ -878,13 +879,9 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     const uint32_t left = range - cb;
                     if (left < KMP_CHUNK) st &= (1ull << (left >> 4)) - 1ull;        /* bits past the range belong to the next wavefront */
 
-                    /* the lane's 16 bytes + the next 20 of the stream */
-                    const uint32_t w4 = wave_shl1(v.x, sgpr(bn.x));
-                    const uint32_t W[10] = {v.x, v.y, v.z, v.w, w4, wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
-                                            wave_shl1(v.w, sgpr(bn.w)), wave_shl1(w4, (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
-                    const uint32_t w[5] = {W[0], W[1], W[2], W[3], W[4]};
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
-                    const uint32_t zm = zero_byte_mask(W[0]) | zero_byte_mask(W[1]) | zero_byte_mask(W[2]) | zero_byte_mask(W[3]);
+                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
                     const uint64_t zl = ballot64(zm != 0u);
                     const bool dead_in = dead;
                     if (zl == 0ull) { if (st != 0ull) dead = false; }
@@ -908,26 +905,36 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     for (int q = 0; q < 4; ++q) {
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
-                            const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
+                            const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
                             const uint32_t word = s_tab[(d0 >> 5) & 0x7FFu];
                             hm |= ((word >> (d0 & 31u)) & 1u) << (4 * q + a);
                         }
                     }
                     if (ballot64(hm != 0u) != 0ull) {
-                        /* largest start index allowed by the strlen() rule (16: no 0x00 in sight) */
-                        int32_t zmax = 15;
-                        if (zl != 0ull || dead_in) zmax = nul_limit(15, w, zl, st, dead_in, lane);
+                        /* keep only the start offsets that can count: no 0x00 before them (strlen rule) and at
+                         * least the shortest pattern still inside the payload */
+                        int32_t lim = min(15, rem - (int32_t)KMP_MULTI_MIN_LEN);
+                        if (zl != 0ull || dead_in) lim = min(lim, nul_limit(15, w, zl, st, dead_in, lane));
+                        hm = (lim < 0) ? 0u : (hm & ((2u << lim) - 1u));
+                        if (ballot64(hm != 0u) != 0ull) {
+                            /* level 2.  Stage the chunk + 32 bytes of halo in this wavefront's LDS window so that a
+                             * lane can fetch the 20 bytes behind ANY of its start offsets, then let every lane walk
+                             * its own hits: iterations = the largest hit count of a lane, not 16. */
+                            uint32_t *win = s_win + wave * (KMP_CHUNK / 4u + 8u);
+                            *reinterpret_cast<uint4 *>(win + lane * 4u) = v;
+                            if (lane < 2u) *reinterpret_cast<uint4 *>(win + KMP_CHUNK / 4u + lane * 4u) = make_uint4(bn.x, bn.y, bn.z, bn.w);
+                            while (ballot64(hm != 0u) != 0ull) {
+                                if (hm != 0u) {
+                                    const uint32_t i = (uint32_t)__builtin_ctz(hm);
+                                    hm &= hm - 1u;
+                                    const uint32_t o = vo0 + i;                         /* byte offset inside the chunk window */
+                                    const uint32_t *src = win + (o >> 2);
+                                    const uint32_t sa = o & 3u;
+                                    uint32_t r[6], T[5];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                                    for (int d = 0; d < 6; ++d) r[d] = src[d];
 #pragma unroll
-                            for (int a = 0; a < 4; ++a) {
-                                const int i = 4 * q + a;
-                                const bool act = ((hm >> i) & 1u) && (i <= zmax) && (i + (int)KMP_MULTI_MIN_LEN <= rem);
-                                if (ballot64(act) == 0ull) continue;
-                                uint32_t T[5];
-#pragma unroll
-                                for (int d = 0; d < 5; ++d) T[d] = a ? __builtin_amdgcn_alignbyte(W[q + d + 1], W[q + d], a) : W[q + d];
-                                if (act) {
+                                    for (int d = 0; d < 5; ++d) T[d] = __builtin_amdgcn_alignbyte(r[d + 1], r[d], sa);
                                     uint32_t e = s_bucket[KMP_MULTI_HASH(T[0] & 0xFFFFu)];
                                     while (e != 0xFFFFu) {
                                         const uint32_t ent = s_entry[e];
@@ -936,7 +943,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                         uint32_t diff = 0u;
 #pragma unroll
                                         for (int d = 0; d < 5; ++d) diff |= (T[d] ^ rec[d]) & rec[5 + d];
-                                        if (diff == 0u && i + (int32_t)rec[10] <= rem) atomicAdd(&s_cnt[uid], 1u);
+                                        if (diff == 0u && (int32_t)(i + rec[10]) <= rem) atomicAdd(&s_cnt[uid], 1u);
                                         e = (ent & 0x8000u) ? 0xFFFFu : e + 1u;
                                     }
                                 }
@@ -1205,7 +1212,7 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
-    const size_t lds = (size_t)(table_words + n_unique) * sizeof(uint32_t);
+    const size_t lds = ((size_t)((table_words + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
     if (a.nontemporal)
         hipLaunchKernelGGL((kmp_scan_multi_kernel<4, true>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, a.arena, a.pkt_len,
                            a.bitmap, plan, tables, table_words, n_unique, a.partials);

@@ -397,9 +397,10 @@ def _device_synth(gm, n, length, sp, lens=None):
     d_arena = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     d_len = torch.from_numpy(ln.astype(np.int32)).cuda()
-    gm.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()            # the zero fill / uploads above ran on torch's stream, the fill runs on the context's
+    gm.set_stream(None)
     gm.synth_fill(d_arena, d_off, d_len, sp)
-    torch.cuda.synchronize()
+    gm.sync()
     return d_arena, d_off, d_len, off, ln, nbytes
 
 

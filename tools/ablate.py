@@ -11,11 +11,10 @@ n, L = 1_000_000, 1500
 needle = b"NEEDLE_16B_PATRN"
 sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
 m = GpuMatcher(0)
-m.set_stream(torch.cuda.current_stream().cuda_stream)
 stride = 1504
 d_arena = torch.zeros(n * stride + 64, dtype=torch.uint8, device="cuda")
 d_off = torch.empty(n, dtype=torch.int64, device="cuda"); d_len = torch.empty(n, dtype=torch.int32, device="cuda")
-m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp)
+torch.cuda.synchronize(); m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp); m.sync()
 m.set_patterns([needle]); m.attach_arena(d_arena, d_off, d_len)
 m.set_option(OPT_DEPTH, 4)
 try:

@@ -25,10 +25,9 @@ for fused in (0, 1, 2):
           f"({a.payload_bytes*len(pats)/np.median(ts)/1e6:.1f} GB/s payload x patterns), launches {t.launches}, nonzero {int((c>0).sum())}")
 n, L = 1_000_000, 1500
 sp = K.SynthParams.make(seed=1234, needle=b"NEEDLE_16B_PATRN", plant_permille=100)
-m.set_stream(torch.cuda.current_stream().cuda_stream)
 d_arena = torch.zeros(n * 1504 + 64, dtype=torch.uint8, device="cuda")
 d_off = torch.empty(n, dtype=torch.int64, device="cuda"); d_len = torch.empty(n, dtype=torch.int32, device="cuda")
-m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp)
+torch.cuda.synchronize(); m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp); m.sync()
 for fused in (0, 1):
   m.set_option(OPT_FUSED, fused)
   for np_ in (2, 4, 16, 97):

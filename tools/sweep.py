@@ -35,8 +35,7 @@ def main():
     needle = b"NEEDLE_16B_PATRN"
     sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
     m = GpuMatcher(0)
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
-    stride = (L + args.align - 1) // args.align * args.align
+        stride = (L + args.align - 1) // args.align * args.align
     if args.zipf:
         rng = np.random.default_rng(4)
         ranks = np.arange(1, 9000 - 64 + 2)
@@ -57,7 +56,9 @@ def main():
         m.fixed_index(d_off, d_len, L, args.align)
         planted = K.synth_count_planted(sp, n, L)
         payload = n * L
+    torch.cuda.synchronize()
     m.synth_fill(d_arena, d_off, d_len, sp)
+    m.sync()
     m.set_patterns([needle])
     m.attach_arena(d_arena, d_off, d_len)
     variants = list(itertools.product([int(x) for x in args.kernels.split(",")], [int(x) for x in args.modes.split(",")], [int(x) for x in args.depths.split(",")],
