@@ -74,6 +74,10 @@ typedef struct kmpgpu_match {
                                         general one-packet-per-wavefront kernel; 2 the packed
                                         streaming kernel whenever the slots are back to back   */
 
+#define KMPGPU_OPT_ACCUMULATE    6   /* 1 = every pass ADDS to the counts buffer instead of
+                                        overwriting it (batches of a streamed capture,
+                                        openmp_task.c:172-175); kmpgpu_counts_reset() zeroes it */
+
 const char *kmpgpu_last_error(void);
 int  kmpgpu_device_count(void);                        /* >= 0, or KMPGPU_EHIP                */
 
@@ -121,6 +125,10 @@ int  kmpgpu_scan(kmpgpu_ctx *ctx, uint64_t *counts_out, kmpgpu_timing *t);
 int  kmpgpu_scan_enqueue(kmpgpu_ctx *ctx, void *d_counts_out);
 /* Device address of the context's own counts buffer. */
 void *kmpgpu_counts_device(kmpgpu_ctx *ctx);
+/* Zero the context's own counts buffer (asynchronous, on the context's stream). */
+int  kmpgpu_counts_reset(kmpgpu_ctx *ctx);
+/* Wait for the context's stream and copy its own counts buffer to the host (uint64_t[n_pat]). */
+int  kmpgpu_counts_read(kmpgpu_ctx *ctx, uint64_t *counts_out);
 int  kmpgpu_sync(kmpgpu_ctx *ctx);
 
 /* Per-launch durations of the scan kernel, measured with HIP events on the launch stream.

@@ -102,6 +102,19 @@ uint64_t kmp_arena_layout(const uint32_t *lens, uint32_t fixed_len, uint64_t n, 
                           uint64_t *off_out, uint32_t *len_out);
 void kmp_arena_free(kmp_arena *a);
 
+/* ---- streamed capture: batches -----------------------------------------------------------------
+ * Replaces the producer of openmp_task.c:126-155 (read up to N packets, extract, hand the batch to
+ * a task).  The caller owns the (pinned) buffers; a batch ends when the next payload would not fit
+ * in cap_bytes / cap_pkts.  The batch is a packed arena in the sense of kmpgpu.h. */
+typedef struct kmp_batch_reader kmp_batch_reader;
+kmp_batch_reader *kmp_batch_open(const char *path, int proto, char errbuf[KMP_PCAP_ERRBUF]);
+/* Returns the number of payloads stored (0 = end of capture), or a negative KMPHOST_E* code
+ * (KMPHOST_EINVAL: a single payload is larger than cap_bytes).  *used_bytes = arena bytes to upload
+ * (slack included), *frames += records read. */
+int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, uint64_t *off, uint32_t *len,
+                       uint64_t cap_pkts, uint64_t *used_bytes, uint64_t *frames);
+void kmp_batch_close(kmp_batch_reader *r);
+
 /* Synthetic fill on the host (same bytes as the device generator, kmp_synth.h). */
 void kmp_synth_fill_host(uint8_t *arena, const uint64_t *off, const uint32_t *len, uint64_t first_pkt_id,
                          uint64_t n, const kmp_synth_params *sp, int threads);

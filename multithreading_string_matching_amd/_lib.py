@@ -94,6 +94,9 @@ HOST_API = {
     "kmp_arena_from_payloads": (C.c_int, [C.POINTER(u8p), u32p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(Arena)]),
     "kmp_arena_layout": (C.c_uint64, [u32p, C.c_uint32, C.c_uint64, C.c_uint32, u64p, u32p]),
     "kmp_arena_free": (None, [C.POINTER(Arena)]),
+    "kmp_batch_open": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p]),
+    "kmp_batch_next": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p]),
+    "kmp_batch_close": (None, [C.c_void_p]),
     "kmp_synth_fill_host": (None, [u8p, u64p, u32p, C.c_uint64, C.c_uint64, C.POINTER(SynthParams), C.c_int]),
     "kmp_synth_count_planted": (C.c_uint64, [u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(SynthParams)]),
     "kmp_report": (None, [C.c_void_p, C.POINTER(Patterns), u64p, C.c_double]),
@@ -116,6 +119,8 @@ GPU_API = {
     "kmpgpu_scan": (C.c_int, [C.c_void_p, u64p, C.POINTER(Timing)]),
     "kmpgpu_scan_enqueue": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kmpgpu_counts_device": (C.c_void_p, [C.c_void_p]),
+    "kmpgpu_counts_reset": (C.c_int, [C.c_void_p]),
+    "kmpgpu_counts_read": (C.c_int, [C.c_void_p, u64p]),
     "kmpgpu_sync": (C.c_int, [C.c_void_p]),
     "kmpgpu_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
     "kmpgpu_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), u32p]),

@@ -1,0 +1,215 @@
+/*
+ * kmp_cli_task.c -- bin/openmp_task: the reference's streaming variant on the MI355X hot path.
+ *
+ *   ./openmp_task <file.pcap> <string.txt> thread_number [tcp/udp]          openmp_task.c:1-2,35-55
+ *
+ * openmp_task.c:126-186 lets one thread read the capture 100 packets at a time and spawns a task per
+ * batch; the tasks add their private counters into the shared ones.  Here the producer (this thread)
+ * reads batches of KMPGPU_BATCH_BYTES (default 64 MiB) into pinned buffers while consumer threads,
+ * one per GPU shard (thread_number), upload and scan them: pcap read || H2D || scan.  Every consumer
+ * alternates between two contexts (own stream, own device buffers) so that the upload of a batch
+ * overlaps the scan of the previous one; the contexts accumulate counts over their batches
+ * (KMPGPU_OPT_ACCUMULATE) and the totals are summed at the end (openmp_task.c:172-175).
+ *
+ * stdout is byte-compatible with the reference (openmp_task.c:190-196).  No CPU fallback: exit code 2
+ * without a gfx950 device.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "kmpgpu.h"
+#include "kmphost.h"
+
+#define SLOTS_PER_SHARD 3
+
+typedef struct slot {
+    uint8_t  *arena;
+    uint64_t *off;
+    uint32_t *len;
+    uint64_t  used, n;
+    int       state;                 /* 0 free, 1 filled */
+} slot;
+
+typedef struct shared {
+    pthread_mutex_t mu;
+    pthread_cond_t  cv;
+    slot           *slots;
+    int             n_slots;
+    int             done;            /* producer finished */
+    uint64_t        next_fill, next_take;     /* ring positions */
+    const kmp_patterns *pats;
+    const uint8_t **pp;
+    int             ndev;
+    int             failed;
+} shared;
+
+typedef struct consumer {
+    shared   *sh;
+    int       id;
+    uint64_t *counts;                /* [pats.n] */
+    double    kernel_ms, h2d_ms;
+    uint64_t  batches, payloads, bytes;
+} consumer;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void die_gpu(const char *what)
+{
+    fprintf(stderr, "%s: %s\n", what, kmpgpu_last_error());
+    exit(2);
+}
+
+static void *consume(void *arg)
+{
+    consumer *me = (consumer *)arg;
+    shared *sh = me->sh;
+    kmpgpu_ctx *ctx[2] = {NULL, NULL};
+    for (int i = 0; i < 2; i++) {
+        if (kmpgpu_init(&ctx[i], me->id % sh->ndev)) die_gpu("kmpgpu_init");
+        if (kmpgpu_set_patterns(ctx[i], sh->pp, sh->pats->len, sh->pats->n)) die_gpu("kmpgpu_set_patterns");
+        if (kmpgpu_set_option(ctx[i], KMPGPU_OPT_ACCUMULATE, 1) || kmpgpu_counts_reset(ctx[i])) die_gpu("kmpgpu_set_option");
+    }
+    int turn = 0;
+    for (;;) {
+        pthread_mutex_lock(&sh->mu);
+        while (sh->next_take == sh->next_fill && !sh->done) pthread_cond_wait(&sh->cv, &sh->mu);
+        if (sh->next_take == sh->next_fill && sh->done) { pthread_mutex_unlock(&sh->mu); break; }
+        slot *s = &sh->slots[sh->next_take % (uint64_t)sh->n_slots];
+        sh->next_take++;
+        pthread_mutex_unlock(&sh->mu);
+
+        kmpgpu_ctx *c = ctx[turn];
+        turn ^= 1;
+        /* waits for this context's previous scan, uploads (the other context's scan keeps running) */
+        if (kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n)) die_gpu("kmpgpu_load_arena");
+        me->batches++; me->payloads += s->n;
+        pthread_mutex_lock(&sh->mu);
+        s->state = 0;                                        /* the pinned buffer may be refilled */
+        pthread_cond_broadcast(&sh->cv);
+        pthread_mutex_unlock(&sh->mu);
+        if (kmpgpu_scan_enqueue(c, NULL)) die_gpu("kmpgpu_scan_enqueue");
+    }
+    for (int i = 0; i < 2; i++) {
+        uint64_t *part = (uint64_t *)calloc(sh->pats->n ? sh->pats->n : 1, sizeof(uint64_t));
+        if (kmpgpu_counts_read(ctx[i], part)) die_gpu("kmpgpu_counts_read");     /* waits for the context's last scan */
+        for (uint32_t k = 0; k < sh->pats->n; k++) me->counts[k] += part[k];
+        free(part);
+        kmpgpu_destroy(ctx[i]);
+    }
+    return NULL;
+}
+
+int main(int argc, char *argv[])
+{
+    int proto = KMP_PROTO_UDP;
+    int shards = 1;
+    if (argc == 4 || argc == 5) {                                            /* openmp_task.c:35 */
+        shards = atoi(argv[3]);                                              /* openmp_task.c:38 */
+        if (argc == 5) {
+            if (strcmp(argv[4], "udp") == 0) proto = KMP_PROTO_UDP;
+            else if (strcmp(argv[4], "tcp") == 0) proto = KMP_PROTO_TCP;
+            else {
+                printf("USAGE ./openmp_task <file.pcap> <string.txt> thread_number [tcp/udp]\n");   /* openmp_task.c:46 */
+                exit(1);
+            }
+        }
+    } else {
+        printf("USAGE: ./openmp_task <file.pcap> <string.txt> [tcp/udp]\n");                       /* openmp_task.c:52 (sic) */
+        exit(1);
+    }
+    if (shards < 1) shards = 1;
+
+    kmp_patterns pats;
+    int rc = kmp_patterns_load(argv[2], &pats);                                                     /* openmp_task.c:57-96 */
+    if (rc == KMPHOST_EIO) { perror("error opening file: "); exit(1); }
+    if (rc) { fprintf(stderr, "error reading pattern file\n"); exit(1); }
+
+    char errbuf[KMP_PCAP_ERRBUF];
+    kmp_batch_reader *rd = kmp_batch_open(argv[1], proto, errbuf);                                 /* openmp_task.c:104-108 */
+    if (!rd) { fprintf(stderr, "error reading pcap file: %s\n", errbuf); exit(1); }
+
+    const int ndev = kmpgpu_device_count();
+    if (ndev <= 0) die_gpu("no MI355X device");
+
+    uint64_t batch_bytes = 64ull << 20;
+    const char *env = getenv("KMPGPU_BATCH_BYTES");
+    if (env && atoll(env) >= (1 << 20)) batch_bytes = (uint64_t)atoll(env);
+    const uint64_t cap_pkts = batch_bytes / 64;
+
+    shared sh;
+    memset(&sh, 0, sizeof sh);
+    pthread_mutex_init(&sh.mu, NULL);
+    pthread_cond_init(&sh.cv, NULL);
+    sh.n_slots = SLOTS_PER_SHARD * shards;
+    sh.slots = (slot *)calloc((size_t)sh.n_slots, sizeof(slot));
+    sh.pats = &pats; sh.ndev = ndev;
+    sh.pp = (const uint8_t **)malloc(sizeof(uint8_t *) * (pats.n ? pats.n : 1));
+    for (uint32_t i = 0; i < pats.n; i++) sh.pp[i] = pats.blob + pats.off[i];
+    for (int i = 0; i < sh.n_slots; i++) {
+        sh.slots[i].arena = (uint8_t *)kmpgpu_host_alloc((size_t)batch_bytes);
+        sh.slots[i].off = (uint64_t *)kmpgpu_host_alloc((size_t)cap_pkts * sizeof(uint64_t));
+        sh.slots[i].len = (uint32_t *)kmpgpu_host_alloc((size_t)cap_pkts * sizeof(uint32_t));
+        if (!sh.slots[i].arena || !sh.slots[i].off || !sh.slots[i].len) die_gpu("kmpgpu_host_alloc");
+    }
+
+    const double t_start = now_s();                                                                 /* openmp_task.c:124 */
+    consumer *cons = (consumer *)calloc((size_t)shards, sizeof(consumer));
+    pthread_t *th = (pthread_t *)calloc((size_t)shards, sizeof(pthread_t));
+    if (pats.n) {
+        for (int r = 0; r < shards; r++) {
+            cons[r].sh = &sh; cons[r].id = r;
+            cons[r].counts = (uint64_t *)calloc(pats.n, sizeof(uint64_t));
+            pthread_create(&th[r], NULL, consume, &cons[r]);
+        }
+    }
+    uint64_t frames = 0, payloads = 0, bytes = 0, batches = 0;
+    for (;;) {                                                                                      /* openmp_task.c:130-155: the producer */
+        slot *s = &sh.slots[sh.next_fill % (uint64_t)sh.n_slots];
+        pthread_mutex_lock(&sh.mu);
+        while (s->state != 0) pthread_cond_wait(&sh.cv, &sh.mu);
+        pthread_mutex_unlock(&sh.mu);
+        const int64_t n = kmp_batch_next(rd, s->arena, batch_bytes, s->off, s->len, cap_pkts, &s->used, &frames);
+        if (n < 0) { fprintf(stderr, "error reading pcap file: a payload exceeds KMPGPU_BATCH_BYTES\n"); exit(1); }
+        if (n == 0) break;
+        s->n = (uint64_t)n;
+        payloads += s->n; batches++;
+        for (uint64_t k = 0; k < s->n; k++) bytes += s->len[k];
+        if (!pats.n) continue;
+        pthread_mutex_lock(&sh.mu);
+        s->state = 1;
+        sh.next_fill++;
+        pthread_cond_broadcast(&sh.cv);
+        pthread_mutex_unlock(&sh.mu);
+    }
+    pthread_mutex_lock(&sh.mu);
+    sh.done = 1;
+    pthread_cond_broadcast(&sh.cv);
+    pthread_mutex_unlock(&sh.mu);
+
+    uint64_t *counts = (uint64_t *)calloc(pats.n ? pats.n : 1, sizeof(uint64_t));
+    if (pats.n)
+        for (int r = 0; r < shards; r++) {
+            pthread_join(th[r], NULL);
+            for (uint32_t i = 0; i < pats.n; i++) counts[i] += cons[r].counts[i];                  /* openmp_task.c:172-175 */
+        }
+    const double t_finish = now_s();                                                                /* openmp_task.c:188 */
+
+    kmp_report(stdout, &pats, counts, t_finish - t_start);                                         /* openmp_task.c:190-196 */
+    fprintf(stderr, "[kmpgpu] streamed %llu frames, %llu payloads, %llu payload bytes in %llu batch(es) of <= %llu MiB over %d shard(s): %.3f s, %.2f GB/s end to end\n",
+            (unsigned long long)frames, (unsigned long long)payloads, (unsigned long long)bytes, (unsigned long long)batches,
+            (unsigned long long)(batch_bytes >> 20), shards, t_finish - t_start, (double)bytes / (t_finish - t_start) / 1e9);
+
+    kmp_batch_close(rd);
+    for (int i = 0; i < sh.n_slots; i++) {
+        kmpgpu_host_free(sh.slots[i].arena); kmpgpu_host_free(sh.slots[i].off); kmpgpu_host_free(sh.slots[i].len);
+    }
+    return 0;
+}

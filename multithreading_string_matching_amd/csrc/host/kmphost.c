@@ -317,6 +317,65 @@ int kmp_arena_from_pcap(const char *path, int proto, kmp_alloc_fn alloc_fn, kmp_
     return KMPHOST_OK;
 }
 
+/* ============================ streamed capture: batches =================================
+ * The producer half of openmp_task.c:126-155. */
+struct kmp_batch_reader {
+    kmp_pcap      *p;
+    int            proto;
+    int            pending;          /* a record has been read but did not fit into the previous batch */
+    uint32_t       cl;
+    const uint8_t *data;
+    int            eof;
+};
+
+kmp_batch_reader *kmp_batch_open(const char *path, int proto, char errbuf[KMP_PCAP_ERRBUF])
+{
+    kmp_pcap *p = kmp_pcap_open(path, errbuf);
+    if (!p) return NULL;
+    kmp_batch_reader *r = (kmp_batch_reader *)calloc(1, sizeof *r);
+    if (!r) { kmp_pcap_close(p); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
+    r->p = p; r->proto = proto;
+    return r;
+}
+
+int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, uint64_t *off, uint32_t *len,
+                       uint64_t cap_pkts, uint64_t *used_bytes, uint64_t *frames)
+{
+    uint64_t n = 0, pos = 0;
+    if (cap_bytes < KMP_ARENA_SLACK + KMP_SLOT_ALIGN) return KMPHOST_EINVAL;
+    const uint64_t room = cap_bytes - KMP_ARENA_SLACK;
+    while (!r->eof) {
+        if (!r->pending) {
+            uint32_t ln;
+            if (kmp_pcap_next(r->p, &r->cl, &ln, &r->data) < 0) { r->eof = 1; break; }   /* openmp_task.c:135 */
+            if (frames) (*frames)++;
+            r->pending = 1;
+        }
+        uint32_t po, pl;
+        const int ok = (r->proto == KMP_PROTO_TCP) ? kmp_extract_tcp(r->data, r->cl, &po, &pl)
+                                                   : kmp_extract_udp(r->data, r->cl, &po, &pl);   /* openmp_task.c:139-142 */
+        if (!ok) { r->pending = 0; continue; }      /* invalid frames cannot match anything (openmp_task.c:150-153 stores " ") */
+        const uint64_t slot = round_up(pl ? pl : 1, KMP_SLOT_ALIGN);
+        if (slot > room) return KMPHOST_EINVAL;
+        if (pos + slot > room || n == cap_pkts) break;           /* keep the record for the next batch */
+        off[n] = pos; len[n] = pl;
+        if (pl) memcpy(arena + pos, r->data + po, pl);
+        if (slot > pl) memset(arena + pos + pl, 0, (size_t)(slot - pl));
+        pos += slot; n++;
+        r->pending = 0;
+    }
+    if (n) memset(arena + pos, 0, KMP_ARENA_SLACK);
+    if (used_bytes) *used_bytes = n ? pos + KMP_ARENA_SLACK : 0;
+    return (int64_t)n;
+}
+
+void kmp_batch_close(kmp_batch_reader *r)
+{
+    if (!r) return;
+    kmp_pcap_close(r->p);
+    free(r);
+}
+
 /* ============================ synthetic payloads ======================================== */
 
 void kmp_synth_fill_host(uint8_t *arena, const uint64_t *off, const uint32_t *len, uint64_t first_pkt_id,

@@ -971,7 +971,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t blocks_x,
                   const uint32_t *__restrict__ pat_ids, const uint32_t *__restrict__ rows,
-                  unsigned long long *__restrict__ counts)
+                  unsigned long long *__restrict__ counts, int accumulate)
 {
     __shared__ unsigned long long s[KMP_BLOCK_WAVES];
     unsigned long long t = 0ull;
@@ -985,7 +985,9 @@ kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t bloc
     if (threadIdx.x == 0u) {
         unsigned long long r = 0ull;
         for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) r += s[i];
-        counts[pat_ids[blockIdx.x]] = r;
+        /* accumulate: counts keep adding up over the batches of a streamed capture (openmp_task.c:172-175) */
+        unsigned long long *dst = counts + pat_ids[blockIdx.x];
+        *dst = accumulate ? *dst + r : r;
     }
 }
 
@@ -1199,10 +1201,11 @@ hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st)
 }
 
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
-                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows)
+                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows, int accumulate)
 {
     if (n_ids == 0) return hipSuccess;
-    hipLaunchKernelGGL(kmp_reduce_kernel, dim3(n_ids), dim3(KMP_BLOCK_THREADS), 0, st, partials, blocks_x, pat_ids, rows, counts);
+    hipLaunchKernelGGL(kmp_reduce_kernel, dim3(n_ids), dim3(KMP_BLOCK_THREADS), 0, st, partials, blocks_x, pat_ids, rows, counts,
+                       accumulate);
     return hipGetLastError();
 }
 

@@ -42,7 +42,8 @@ hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned
 hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
                            void *plan, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
-                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr);
+                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr,
+                             int accumulate = 0);
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
                                  hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,

@@ -85,6 +85,7 @@ struct kmpgpu_ctx {
     uint64_t        uni_off0 = 0;
     uint32_t        uni_stride = 0, uni_len = 0;
     void           *owned_arena = nullptr, *owned_off = nullptr, *owned_len = nullptr;
+    uint64_t        cap_arena = 0, cap_pkts = 0;      /* capacities of the owned buffers (reused by the next load) */
 
     /* results */
     unsigned long long *d_partials = nullptr;
@@ -96,7 +97,7 @@ struct kmpgpu_ctx {
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, ablate = 0, fused = 2 /* auto */;
+    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, ablate = 0, fused = 2 /* auto */, accumulate = 0;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -152,12 +153,15 @@ int ensure_partials(kmpgpu_ctx *c, size_t elems)
     return KMPGPU_OK;
 }
 
-void release_arena(kmpgpu_ctx *c)
+void release_arena(kmpgpu_ctx *c, bool keep_buffers = false)
 {
-    if (c->owned_arena) (void)hipFree(c->owned_arena);
-    if (c->owned_off) (void)hipFree(c->owned_off);
-    if (c->owned_len) (void)hipFree(c->owned_len);
-    c->owned_arena = c->owned_off = c->owned_len = nullptr;
+    if (!keep_buffers) {
+        if (c->owned_arena) (void)hipFree(c->owned_arena);
+        if (c->owned_off) (void)hipFree(c->owned_off);
+        if (c->owned_len) (void)hipFree(c->owned_len);
+        c->owned_arena = c->owned_off = c->owned_len = nullptr;
+        c->cap_arena = c->cap_pkts = 0;
+    }
     c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
     c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
     c->uniform = false; c->packed = false; c->plan_waves = 0;
@@ -187,7 +191,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     if (!c->d_off && c->n_pkts) return fail(KMPGPU_ESTATE, "kmpgpu_scan: no arena loaded");
     uint32_t nl = 0;
     if (c->n_pkts == 0) {
-        HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * c->n_pat, c->stream));
+        if (!c->accumulate) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * c->n_pat, c->stream));
         if (launches) *launches = 0;
         return KMPGPU_OK;
     }
@@ -254,7 +258,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         HIP_TRY(record(e0, e1));
         HIP_TRY(kmp_launch_scan_multi(f, c->d_multi_tables, c->multi_words, c->n_multi_unique, c->stream));
         if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-        HIP_TRY(kmp_launch_reduce(c->d_partials, bx, c->d_multi_ids, c->n_multi, d_out, c->stream, c->d_multi_rows));
+        HIP_TRY(kmp_launch_reduce(c->d_partials, bx, c->d_multi_ids, c->n_multi, d_out, c->stream, c->d_multi_rows, c->accumulate));
         ++nl;
         part_base = c->n_multi_unique;
         ids = c->d_rest_ids; n_long = c->rest_long; n_short = c->rest_short;
@@ -275,7 +279,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
                 return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets needs an arena whose slots are back to back (as kmp_arena builds them)");
             HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream));
+            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream, nullptr, c->accumulate));
             ++nl;
         }
     }
@@ -376,6 +380,8 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
     case KMPGPU_OPT_FUSED:
         if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "fused must be 0, 1 or 2");
         c->fused = (int)value; return KMPGPU_OK;
+    case KMPGPU_OPT_ACCUMULATE:
+        c->accumulate = value ? 1 : 0; return KMPGPU_OK;
     case KMPGPU_OPT_KERNEL:
         if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "kernel selection must be 0, 1 or 2");
         c->kernel_sel = (int)value; return KMPGPU_OK;
@@ -533,13 +539,18 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
     }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    release_arena(c);
+    /* streamed captures load batch after batch: keep the device buffers when the next batch fits */
+    const bool reuse = c->owned_arena && c->cap_arena >= arena_bytes && c->cap_pkts >= n_pkts && n_pkts > 0;
+    release_arena(c, reuse);
     c->last.h2d_ms = 0;
     if (n_pkts == 0) return KMPGPU_OK;
     if (arena_bytes < 16) return fail(KMPGPU_EINVAL, "arena smaller than 16 bytes");
-    HIP_TRY(hipMalloc(&c->owned_arena, arena_bytes));
-    HIP_TRY(hipMalloc(&c->owned_off, n_pkts * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&c->owned_len, n_pkts * sizeof(uint32_t)));
+    if (!reuse) {
+        HIP_TRY(hipMalloc(&c->owned_arena, arena_bytes));
+        HIP_TRY(hipMalloc(&c->owned_off, n_pkts * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&c->owned_len, n_pkts * sizeof(uint32_t)));
+        c->cap_arena = arena_bytes; c->cap_pkts = n_pkts;
+    }
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     HIP_TRY(hipMemcpyAsync(c->owned_arena, arena, arena_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->owned_off, pkt_off, n_pkts * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -602,6 +613,26 @@ int kmpgpu_scan_enqueue(kmpgpu_ctx *c, void *d_counts_out)
 }
 
 void *kmpgpu_counts_device(kmpgpu_ctx *c) { return c ? (void *)c->d_counts : nullptr; }
+
+int kmpgpu_counts_reset(kmpgpu_ctx *c)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_counts_reset: ctx is NULL");
+    if (!c->d_counts) return fail(KMPGPU_ESTATE, "kmpgpu_counts_reset: no patterns set");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * (c->n_pat ? c->n_pat : 1), c->stream));
+    return KMPGPU_OK;
+}
+
+int kmpgpu_counts_read(kmpgpu_ctx *c, uint64_t *counts_out)
+{
+    if (!c || (!counts_out && c->n_pat)) return fail(KMPGPU_EINVAL, "kmpgpu_counts_read: NULL argument");
+    if (!c->d_counts) return fail(KMPGPU_ESTATE, "kmpgpu_counts_read: no patterns set");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint64_t) * c->n_pat, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->n_pat) memcpy(counts_out, c->h_counts, sizeof(uint64_t) * c->n_pat);
+    return KMPGPU_OK;
+}
 
 int kmpgpu_sync(kmpgpu_ctx *c)
 {

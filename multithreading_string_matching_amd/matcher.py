@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import KmpGpuError, Match, SynthParams, Timing, gpu_check, u8p, u32p, u64p
 from .host import HostArena
 
-OPT_MODE, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_NONTEMPORAL = 1, 2, 3, 4, 5, 100
+OPT_MODE, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_ACCUMULATE, OPT_NONTEMPORAL = 1, 2, 3, 4, 5, 6, 100
 KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED = 0, 1, 2
 MODE_FILTER, MODE_AUTOMATON = 0, 1
 
@@ -95,6 +95,9 @@ class GpuMatcher:
         """Enqueue one pass; counts land in d_counts (torch int64 CUDA tensor) or the context buffer."""
         ptr = d_counts.data_ptr() if d_counts is not None else None
         gpu_check(self._g.kmpgpu_scan_enqueue(self._ctx, ptr), "kmpgpu_scan_enqueue")
+
+    def counts_reset(self) -> None:
+        gpu_check(self._g.kmpgpu_counts_reset(self._ctx), "kmpgpu_counts_reset")
 
     def sync(self) -> None:
         gpu_check(self._g.kmpgpu_sync(self._ctx), "kmpgpu_sync")

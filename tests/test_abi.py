@@ -37,5 +37,5 @@ def test_host_abi_exports_every_declared_symbol():
 
 def test_binaries_exist():
     K.build()
-    for b in ("serial", "openmp_data"):
+    for b in ("serial", "openmp_data", "openmp_task"):
         assert os.access(os.path.join(_lib.BINDIR, b), os.X_OK)

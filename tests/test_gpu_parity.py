@@ -534,6 +534,36 @@ def test_cli_openmp_data_form(fixture_counts, tokens, shards):
     assert r.returncode == 0 and _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
 
 
+@pytest.mark.parametrize("shards,batch", [("1", "1048576"), ("2", "1048576"), ("3", "67108864")])
+@pytest.mark.parametrize("key", ["big_udp.pcap:udp", "very_big_udp.pcap:udp", "udp_1000.pcap:tcp"])
+def test_cli_openmp_task_streaming(fixture_counts, tokens, key, shards, batch):
+    """bin/openmp_task: batches of the capture scanned while the next ones are read (openmp_task.c:126-186)."""
+    fx = fixture_counts["fixtures"][key]
+    exe = os.path.join(_lib.BINDIR, "openmp_task")
+    env = dict(os.environ, KMPGPU_BATCH_BYTES=batch)
+    r = subprocess.run([exe, os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt"), shards, fx["mode"]],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
+def test_accumulate_option(gm, oracle):
+    pats = [b"ab", b"abcab", b"c"]
+    rng = random.Random(3)
+    batches = [[bytes(rng.choice(b"abc") for _ in range(rng.randrange(0, 900))) for _ in range(300)] for _ in range(3)]
+    want = sum(oracle.count_payloads(b, pats) for b in batches)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    gm.set_option(6, 1)                      # KMPGPU_OPT_ACCUMULATE
+    gm.counts_reset()
+    for b in batches:
+        gm.load_arena(K.HostArena.from_payloads(b))
+        got = gm.scan()[0]
+    gm.set_option(6, 0)
+    assert got.tolist() == want.tolist()
+    assert gm.scan()[0].tolist() == oracle.count_payloads(batches[-1], pats).tolist()      # overwrite again
+
+
 def test_cli_offsets_file(tokens, fixture_counts, tmp_path):
     out = tmp_path / "offsets.csv"
     exe = os.path.join(_lib.BINDIR, "openmp_data")

@@ -131,6 +131,36 @@ def test_arena_from_pcap(oracle, fixture_counts, tokens, key):
     assert got.tolist() == fx["counts"]
 
 
+@pytest.mark.parametrize("cap_bytes,cap_pkts", [(1 << 20, 1 << 16), (4096, 1 << 16), (1 << 20, 7), (600, 3)])
+def test_batch_reader_equals_whole_arena(cap_bytes, cap_pkts):
+    """openmp_task.c:130-155 producer: the batches together hold exactly the payloads of the one-shot arena."""
+    import ctypes as C
+    L = _lib.host_lib()
+    whole = K.HostArena.from_pcap(os.path.join(DATA, "udp_1000.pcap"), "udp")
+    err = C.create_string_buffer(256)
+    rd = L.kmp_batch_open(os.path.join(DATA, "udp_1000.pcap").encode(), 0, err)
+    assert rd
+    arena = np.zeros(cap_bytes, dtype=np.uint8)
+    off = np.zeros(cap_pkts, dtype=np.uint64)
+    ln = np.zeros(cap_pkts, dtype=np.uint32)
+    used, frames = C.c_uint64(), C.c_uint64()
+    got = []
+    batches = 0
+    while True:
+        n = L.kmp_batch_next(rd, arena.ctypes.data, cap_bytes, off.ctypes.data, ln.ctypes.data, cap_pkts, C.byref(used), C.byref(frames))
+        assert n >= 0
+        if n == 0:
+            break
+        batches += 1
+        assert n <= cap_pkts and used.value <= cap_bytes and np.all(off[:n] % 16 == 0)
+        assert np.all(off[1:n] == off[:n - 1] + np.maximum(16, (ln[:n - 1].astype(np.uint64) + 15) // 16 * 16))    # packed
+        for k in range(n):
+            got.append(arena[int(off[k]):int(off[k]) + int(ln[k])].tobytes())
+    L.kmp_batch_close(rd)
+    assert frames.value == whole.n_frames and got == [whole.payload(k) for k in range(whole.n_pkts)]
+    assert batches > 1 or cap_bytes >= whole.nbytes
+
+
 def test_arena_from_payloads_roundtrip():
     pls = [b"", b"x", b"hello world", b"a" * 16, b"b" * 17, b"", b"c" * 5000]
     a = K.HostArena.from_payloads(pls)
@@ -195,6 +225,10 @@ def test_cli_usage_and_file_errors(tmp_path):
     assert (r.returncode, r.stdout) == (1, "USAGE: ./openmp_data <file.pcap> <string.txt> thread_number [tcp/udp]\n")
     r = _run("openmp_data", pcap, strings, "2", "sctp")
     assert (r.returncode, r.stdout) == (1, "USAGE ./openmp_data <file.pcap> <string.txt> thread_number [tcp/udp]\n")
+    r = _run("openmp_task", pcap, strings)
+    assert (r.returncode, r.stdout) == (1, "USAGE: ./openmp_task <file.pcap> <string.txt> [tcp/udp]\n")      # sic, openmp_task.c:52
+    r = _run("openmp_task", pcap, strings, "2", "sctp")
+    assert (r.returncode, r.stdout) == (1, "USAGE ./openmp_task <file.pcap> <string.txt> thread_number [tcp/udp]\n")
     r = _run("serial", pcap, str(tmp_path / "nope.txt"))
     assert r.returncode == 1 and r.stderr.startswith("error opening file: : ") and r.stdout == ""
     r = _run("serial", str(tmp_path / "nope.pcap"), strings)
