@@ -109,6 +109,13 @@ int  kmpgpu_set_patterns(kmpgpu_ctx *ctx, const uint8_t *const *pat, const uint3
 int  kmpgpu_load_arena(kmpgpu_ctx *ctx, const uint8_t *arena, uint64_t arena_bytes,
                        const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n_pkts);
 
+/* Replaces the read loop AND the extraction phase (serial.c:115-141; openmp_data.c:128-147): upload the
+ * raw capture file + the position of its frames (kmp_frames_from_pcap) and let the GPU apply the
+ * dump_UDP_packet / dump_TCP_packet rules (packet_dumping.h:87-188) and pack the accepted payloads into
+ * the context's arena.  tcp: 0 = UDP rule, 1 = TCP rule.  *n_payloads = payloads accepted. */
+int  kmpgpu_load_frames(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
+                        const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads);
+
 /* Same, for an arena already resident in device memory (borrowed; same contract, checked by a
  * device-side pass).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*. */
 int  kmpgpu_attach_arena(kmpgpu_ctx *ctx, const void *d_arena, uint64_t arena_bytes,
@@ -155,6 +162,10 @@ int  kmpgpu_fixed_index(kmpgpu_ctx *ctx, void *d_pkt_off, void *d_pkt_len, uint6
 
 /* What the arena currently attached/loaded holds. */
 int  kmpgpu_arena_info(kmpgpu_ctx *ctx, uint64_t *n_pkts, uint64_t *payload_bytes);
+/* Copy the context's device arena + index back to host buffers (tests: the on-device extraction must
+ * build exactly the arena the host builds).  Buffers sized from kmpgpu_arena_info / arena_bytes. */
+int  kmpgpu_arena_download(kmpgpu_ctx *ctx, uint8_t *arena_out, uint64_t arena_cap, uint64_t *arena_bytes,
+                           uint64_t *pkt_off_out, uint32_t *pkt_len_out);
 
 #ifdef __cplusplus
 }

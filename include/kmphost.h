@@ -102,6 +102,22 @@ uint64_t kmp_arena_layout(const uint32_t *lens, uint32_t fixed_len, uint64_t n, 
                           uint64_t *off_out, uint32_t *len_out);
 void kmp_arena_free(kmp_arena *a);
 
+/* ---- raw frames for on-device extraction ------------------------------------------------------
+ * The capture file as it is + where its frames lie: everything the host does when the payload
+ * extraction (openmp_data.c:128-147) runs on the GPU (kmpgpu_load_frames).  Walking the record
+ * headers is the only sequential part of a pcap file. */
+typedef struct kmp_frames {
+    uint8_t  *bytes;          /* the whole savefile                                  */
+    uint64_t  nbytes;
+    uint64_t *off;            /* off[f]: first byte of frame f inside bytes          */
+    uint32_t *caplen;         /* caplen[f]: captured bytes of frame f                */
+    uint64_t  n;
+    kmp_free_fn free_fn;
+} kmp_frames;
+int  kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn, kmp_frames *out,
+                          char errbuf[KMP_PCAP_ERRBUF]);
+void kmp_frames_free(kmp_frames *f);
+
 /* ---- streamed capture: batches -----------------------------------------------------------------
  * Replaces the producer of openmp_task.c:126-155 (read up to N packets, extract, hand the batch to
  * a task).  The caller owns the (pinned) buffers; a batch ends when the next payload would not fit

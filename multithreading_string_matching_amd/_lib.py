@@ -67,6 +67,11 @@ class Arena(C.Structure):
     ]
 
 
+class Frames(C.Structure):
+    """kmp_frames (include/kmphost.h)."""
+    _fields_ = [("bytes", u8p), ("nbytes", C.c_uint64), ("off", u64p), ("caplen", u32p), ("n", C.c_uint64), ("free_fn", C.c_void_p)]
+
+
 class Timing(C.Structure):
     """kmpgpu_timing (include/kmpgpu.h)."""
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
@@ -94,6 +99,8 @@ HOST_API = {
     "kmp_arena_from_payloads": (C.c_int, [C.POINTER(u8p), u32p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(Arena)]),
     "kmp_arena_layout": (C.c_uint64, [u32p, C.c_uint32, C.c_uint64, C.c_uint32, u64p, u32p]),
     "kmp_arena_free": (None, [C.POINTER(Arena)]),
+    "kmp_frames_from_pcap": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(Frames), C.c_char_p]),
+    "kmp_frames_free": (None, [C.POINTER(Frames)]),
     "kmp_batch_open": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p]),
     "kmp_batch_next": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p]),
     "kmp_batch_close": (None, [C.c_void_p]),
@@ -115,6 +122,8 @@ GPU_API = {
     "kmpgpu_host_free": (None, [C.c_void_p]),
     "kmpgpu_set_patterns": (C.c_int, [C.c_void_p, C.POINTER(u8p), u32p, C.c_uint32]),
     "kmpgpu_load_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kmpgpu_load_frames": (C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, u32p, C.c_uint64, C.c_int, u64p]),
+    "kmpgpu_arena_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p, C.c_void_p]),
     "kmpgpu_attach_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
     "kmpgpu_scan": (C.c_int, [C.c_void_p, u64p, C.POINTER(Timing)]),
     "kmpgpu_scan_enqueue": (C.c_int, [C.c_void_p, C.c_void_p]),

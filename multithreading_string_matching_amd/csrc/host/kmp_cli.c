@@ -11,6 +11,9 @@
  * stdout is byte-compatible with the reference (serial.c:163-169); throughput details go to
  * stderr.  There is no CPU fallback: without a gfx950 device the program fails with exit code 2.
  *
+ * KMPGPU_DEVICE_EXTRACT=1: the raw capture is uploaded and the payload extraction
+ * (openmp_data.c:128-147, packet_dumping.h:87-188) runs on the GPU (kmpgpu_load_frames).
+ *
  * Extension (the reference prints counts only, serial.c:163-166): with the environment variable
  * KMPGPU_OFFSETS_FILE=<path> every match is also written to <path> as "payload,offset,pattern"
  * lines (payload = index among the extracted payloads, pattern = index in the pattern file).
@@ -101,7 +104,15 @@ int main(int argc, char *argv[])
 #endif
     char errbuf[KMP_PCAP_ERRBUF];
     kmp_arena arena;
-    rc = kmp_arena_from_pcap(pcap_path, proto, kmpgpu_host_alloc, kmpgpu_host_free, &arena, errbuf);   /* serial.c:91-141 */
+    kmp_frames frames;
+    memset(&arena, 0, sizeof arena);
+    memset(&frames, 0, sizeof frames);
+    const char *dx = getenv("KMPGPU_DEVICE_EXTRACT");
+    const int device_extract = dx && dx[0] == '1';
+    if (device_extract)
+        rc = kmp_frames_from_pcap(pcap_path, kmpgpu_host_alloc, kmpgpu_host_free, &frames, errbuf);
+    else
+        rc = kmp_arena_from_pcap(pcap_path, proto, kmpgpu_host_alloc, kmpgpu_host_free, &arena, errbuf);   /* serial.c:91-141 */
     if (rc == KMPHOST_EIO || rc == KMPHOST_EFORMAT) {
         fprintf(stderr, "error reading pcap file: %s\n", errbuf);           /* serial.c:93 */
         exit(1);
@@ -123,7 +134,31 @@ int main(int argc, char *argv[])
     for (uint32_t i = 0; i < pats.n; i++) pp[i] = pats.blob + pats.off[i];
 
     double kernel_ms = 0, h2d_ms = 0;
-    if (pats.n && arena.n_pkts) {
+    if (pats.n && device_extract && frames.n) {
+        /* frames split like mpi_dumping.c:149-157; every shard extracts and counts its own frames */
+        if ((uint64_t)shards > frames.n) shards = (int)frames.n;
+        uint64_t lo = 0;
+        for (int r = 0; r < shards; r++) {
+            const uint64_t cnt = frames.n / (uint64_t)shards + (r == 0 ? frames.n % (uint64_t)shards : 0);
+            kmpgpu_ctx *ctx;
+            kmpgpu_timing t;
+            uint64_t np = 0;
+            if (kmpgpu_init(&ctx, r % ndev)) die_gpu("kmpgpu_init");
+            if (kmpgpu_set_patterns(ctx, pp, pats.len, pats.n)) die_gpu("kmpgpu_set_patterns");
+            if (kmpgpu_load_frames(ctx, frames.bytes, frames.nbytes, frames.off + lo, frames.caplen + lo, cnt, proto == KMP_PROTO_TCP, &np))
+                die_gpu("kmpgpu_load_frames");
+            if (kmpgpu_scan(ctx, part, &t)) die_gpu("kmpgpu_scan");
+            uint64_t pb = 0;
+            kmpgpu_arena_info(ctx, NULL, &pb);
+            arena.n_pkts += np; arena.payload_bytes += pb;
+            for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];
+            if (t.kernel_ms > kernel_ms) kernel_ms = t.kernel_ms;
+            h2d_ms += t.h2d_ms;
+            kmpgpu_destroy(ctx);
+            lo += cnt;
+        }
+        arena.n_frames = frames.n;
+    } else if (pats.n && arena.n_pkts) {
         if ((uint64_t)shards > arena.n_pkts) shards = (int)arena.n_pkts;
         kmpgpu_ctx **ctx = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *ctx);
         uint64_t *reb = (uint64_t *)malloc(sizeof(uint64_t) * arena.n_pkts);
@@ -187,6 +222,7 @@ int main(int argc, char *argv[])
     }
     free(counts); free(part); free(pp);
     kmp_arena_free(&arena);
+    kmp_frames_free(&frames);
     kmp_patterns_free(&pats);
     return 0;
 }

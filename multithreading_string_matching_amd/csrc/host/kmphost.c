@@ -317,6 +317,64 @@ int kmp_arena_from_pcap(const char *path, int proto, kmp_alloc_fn alloc_fn, kmp_
     return KMPHOST_OK;
 }
 
+/* ============================ raw frames (on-device extraction) ========================= */
+
+int kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn, kmp_frames *out,
+                         char errbuf[KMP_PCAP_ERRBUF])
+{
+    memset(out, 0, sizeof *out);
+    if (errbuf) errbuf[0] = 0;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: %s", path, strerror(errno)); return KMPHOST_EIO; }
+    fseek(fp, 0, SEEK_END);
+    const long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (sz < 24) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "truncated dump file; tried to read 24 file header bytes"); return KMPHOST_EIO; }
+    out->free_fn = alloc_fn ? free_fn : free;
+    out->nbytes = (uint64_t)sz;
+    out->bytes = (uint8_t *)(alloc_fn ? alloc_fn((size_t)sz + 64) : malloc((size_t)sz + 64));
+    if (!out->bytes) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return KMPHOST_ENOMEM; }
+    if (fread(out->bytes, 1, (size_t)sz, fp) != (size_t)sz) {
+        fclose(fp); kmp_frames_free(out);
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: short read", path);
+        return KMPHOST_EIO;
+    }
+    fclose(fp);
+    memset(out->bytes + sz, 0, 64);
+    uint32_t magic;
+    memcpy(&magic, out->bytes, 4);
+    int swap;
+    if (magic == 0xA1B2C3D4u || magic == 0xA1B23C4Du) swap = 0;
+    else if (bswap32(magic) == 0xA1B2C3D4u || bswap32(magic) == 0xA1B23C4Du) swap = 1;
+    else { kmp_frames_free(out); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "unknown file format"); return KMPHOST_EFORMAT; }
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t pos = 24, n = 0;
+        while (pos + 16 <= (uint64_t)sz) {
+            uint32_t cl;
+            memcpy(&cl, out->bytes + pos + 8, 4);
+            if (swap) cl = bswap32(cl);
+            if (cl > (64u << 20) || pos + 16 + cl > (uint64_t)sz) break;      /* truncated / corrupt record ends the walk (serial.c:115) */
+            if (pass) { out->off[n] = pos + 16; out->caplen[n] = cl; }
+            pos += 16 + (uint64_t)cl; n++;
+        }
+        if (!pass) {
+            out->n = n;
+            out->off = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+            out->caplen = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+            if (!out->off || !out->caplen) { kmp_frames_free(out); return KMPHOST_ENOMEM; }
+        }
+    }
+    return KMPHOST_OK;
+}
+
+void kmp_frames_free(kmp_frames *f)
+{
+    if (!f) return;
+    if (f->bytes && f->free_fn) f->free_fn(f->bytes);
+    free(f->off); free(f->caplen);
+    memset(f, 0, sizeof *f);
+}
+
 /* ============================ streamed capture: batches =================================
  * The producer half of openmp_task.c:126-155. */
 struct kmp_batch_reader {

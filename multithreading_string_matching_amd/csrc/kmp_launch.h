@@ -46,6 +46,11 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
                              int accumulate = 0);
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
                                  hipStream_t st);
+size_t kmp_extract_ws_bytes(uint64_t n_frames);
+hipError_t kmp_launch_extract_phase1(const uint8_t *file, const uint64_t *frame_off, const uint32_t *caplen, uint64_t n, int tcp,
+                                     uint8_t *ws, unsigned long long *totals, hipStream_t st);
+hipError_t kmp_launch_extract_phase2(const uint8_t *file, const uint64_t *frame_off, uint64_t n, uint8_t *ws, uint64_t n_pkts,
+                                     uint8_t *arena, uint64_t *pkt_off, uint32_t *pkt_len, uint64_t *src_off, hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,
                                uint32_t *err, unsigned long long *payload_bytes, hipStream_t st);
 hipError_t kmp_launch_synth_fill(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t first_pkt_id,

@@ -570,6 +570,96 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
     return prepare_packed(c);
 }
 
+/* Shared tail of the loaders that produce the index on the device: contract + uniform/packed
+ * detection + payload sum from kmp_validate_index_kernel, then the packed kernels' side tables. */
+static int finish_device_index(kmpgpu_ctx *c, const char *who)
+{
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_sum, 0, 6 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(kmp_launch_validate(c->d_off, c->d_len, c->n_pkts, c->arena_bytes, c->d_err, c->d_sum, c->stream));
+    uint32_t err[2] = {0, 0};
+    unsigned long long info[6] = {0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(info, c->d_sum, sizeof info, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err[0]) return fail(KMPGPU_EINVAL, "%s: the payload index violates the layout contract (flags %u)", who, err[0]);
+    c->payload_bytes = info[0];
+    c->uniform = ((err[1] & 1u) == 0) && info[2] >= 16 && info[2] < (1ull << 31);
+    c->uni_off0 = info[1]; c->uni_stride = (uint32_t)info[2]; c->uni_len = (uint32_t)info[3];
+    c->packed = (err[1] & 2u) == 0;
+    c->span_end = info[4];
+    return prepare_packed(c);
+}
+
+int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
+                       const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: ctx is NULL");
+    if (n_frames && (!file_bytes || !frame_off || !frame_caplen)) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: NULL buffers");
+    for (uint64_t f = 0; f < n_frames; f++)
+        if (frame_off[f] > file_nbytes || frame_caplen[f] > file_nbytes - frame_off[f])
+            return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: frame %llu lies outside the file buffer", (unsigned long long)f);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    release_arena(c);
+    c->last.h2d_ms = 0;
+    if (n_payloads) *n_payloads = 0;
+    if (n_frames == 0) return KMPGPU_OK;
+
+    uint8_t *d_file = nullptr, *d_ws = nullptr;
+    uint64_t *d_foff = nullptr, *d_src = nullptr;
+    uint32_t *d_cl = nullptr;
+    unsigned long long *d_tot = nullptr;
+    int rc = KMPGPU_OK;
+    auto cleanup = [&]() {
+        if (d_file) (void)hipFree(d_file);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_foff) (void)hipFree(d_foff);
+        if (d_src) (void)hipFree(d_src);
+        if (d_cl) (void)hipFree(d_cl);
+        if (d_tot) (void)hipFree(d_tot);
+    };
+#define KMP_TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(KMPGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    KMP_TRY2(hipMalloc(&d_file, file_nbytes + 64));
+    KMP_TRY2(hipMalloc(&d_foff, n_frames * sizeof(uint64_t)));
+    KMP_TRY2(hipMalloc(&d_cl, n_frames * sizeof(uint32_t)));
+    KMP_TRY2(hipMalloc(&d_ws, kmp_extract_ws_bytes(n_frames)));
+    KMP_TRY2(hipMalloc(&d_tot, 2 * sizeof(unsigned long long)));
+    KMP_TRY2(hipEventRecord(c->ev[0], c->stream));
+    KMP_TRY2(hipMemcpyAsync(d_file, file_bytes, file_nbytes, hipMemcpyHostToDevice, c->stream));
+    KMP_TRY2(hipMemcpyAsync(d_foff, frame_off, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    KMP_TRY2(hipMemcpyAsync(d_cl, frame_caplen, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    KMP_TRY2(hipEventRecord(c->ev[1], c->stream));
+    KMP_TRY2(kmp_launch_extract_phase1(d_file, d_foff, d_cl, n_frames, tcp, d_ws, d_tot, c->stream));
+    unsigned long long tot[2] = {0, 0};
+    KMP_TRY2(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+    KMP_TRY2(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    KMP_TRY2(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->last.h2d_ms = ms;
+    const uint64_t n_pkts = tot[1], arena_bytes = tot[0] + 64;
+    if (n_pkts) {
+        KMP_TRY2(hipMalloc(&c->owned_arena, arena_bytes));
+        KMP_TRY2(hipMalloc(&c->owned_off, n_pkts * sizeof(uint64_t)));
+        KMP_TRY2(hipMalloc(&c->owned_len, n_pkts * sizeof(uint32_t)));
+        KMP_TRY2(hipMalloc(&d_src, n_pkts * sizeof(uint64_t)));
+        c->cap_arena = arena_bytes; c->cap_pkts = n_pkts;
+        KMP_TRY2(hipMemsetAsync((uint8_t *)c->owned_arena + tot[0], 0, 64, c->stream));
+        KMP_TRY2(kmp_launch_extract_phase2(d_file, d_foff, n_frames, d_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
+                                           (uint32_t *)c->owned_len, d_src, c->stream));
+        KMP_TRY2(hipStreamSynchronize(c->stream));
+    }
+#undef KMP_TRY2
+    cleanup();
+    if (n_payloads) *n_payloads = n_pkts;
+    if (n_pkts == 0) return KMPGPU_OK;
+    c->d_arena = (const uint8_t *)c->owned_arena;
+    c->d_off = (const uint64_t *)c->owned_off;
+    c->d_len = (const uint32_t *)c->owned_len;
+    c->arena_bytes = arena_bytes; c->n_pkts = n_pkts;
+    return finish_device_index(c, "kmpgpu_load_frames");
+}
+
 int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes, const void *d_pkt_off,
                         const void *d_pkt_len, uint64_t n_pkts)
 {
@@ -760,6 +850,23 @@ int kmpgpu_arena_info(kmpgpu_ctx *c, uint64_t *n_pkts, uint64_t *payload_bytes)
     if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_arena_info: ctx is NULL");
     if (n_pkts) *n_pkts = c->n_pkts;
     if (payload_bytes) *payload_bytes = c->payload_bytes;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_arena_download(kmpgpu_ctx *c, uint8_t *arena_out, uint64_t arena_cap, uint64_t *arena_bytes, uint64_t *pkt_off_out,
+                          uint32_t *pkt_len_out)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_arena_download: ctx is NULL");
+    if (arena_bytes) *arena_bytes = c->arena_bytes;
+    if (c->n_pkts == 0) return KMPGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (arena_out) {
+        if (arena_cap < c->arena_bytes) return fail(KMPGPU_EINVAL, "kmpgpu_arena_download: buffer too small");
+        HIP_TRY(hipMemcpy(arena_out, c->d_arena, c->arena_bytes, hipMemcpyDeviceToHost));
+    }
+    if (pkt_off_out) HIP_TRY(hipMemcpy(pkt_off_out, c->d_off, c->n_pkts * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (pkt_len_out) HIP_TRY(hipMemcpy(pkt_len_out, c->d_len, c->n_pkts * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return KMPGPU_OK;
 }
 

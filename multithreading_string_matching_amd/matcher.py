@@ -77,6 +77,36 @@ class GpuMatcher:
                                               d_len.data_ptr(), n), "kmpgpu_attach_arena")
         self._keep = (d_arena, d_off, d_len)
 
+    def load_pcap_frames(self, path: str, proto: str = "udp") -> int:
+        """Upload the raw capture and extract the payloads on the GPU (kmpgpu_load_frames).
+        Returns the number of payloads accepted."""
+        H = _lib.host_lib()
+        fr = _lib.Frames()
+        err = C.create_string_buffer(_lib.KMP_PCAP_ERRBUF)
+        rc = H.kmp_frames_from_pcap(path.encode(), None, None, C.byref(fr), err)
+        if rc:
+            raise _lib.KmpHostError(f"error reading pcap file: {err.value.decode(errors='replace')} ({rc})")
+        try:
+            n = C.c_uint64()
+            gpu_check(self._g.kmpgpu_load_frames(self._ctx, fr.bytes, fr.nbytes, fr.off, fr.caplen, fr.n, 1 if proto == "tcp" else 0,
+                                                 C.byref(n)), "kmpgpu_load_frames")
+            self._keep = None
+            return int(n.value)
+        finally:
+            H.kmp_frames_free(C.byref(fr))
+
+    def arena_download(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        n, _ = self.arena_info()
+        nb = C.c_uint64()
+        gpu_check(self._g.kmpgpu_arena_download(self._ctx, None, 0, C.byref(nb), None, None), "kmpgpu_arena_download")
+        a = np.zeros(max(int(nb.value), 1), dtype=np.uint8)
+        off = np.zeros(max(n, 1), dtype=np.uint64)
+        ln = np.zeros(max(n, 1), dtype=np.uint32)
+        if n:
+            gpu_check(self._g.kmpgpu_arena_download(self._ctx, a.ctypes.data, a.size, C.byref(nb), off.ctypes.data, ln.ctypes.data),
+                      "kmpgpu_arena_download")
+        return a[: int(nb.value)], off[:n], ln[:n]
+
     def arena_info(self) -> Tuple[int, int]:
         n, b = C.c_uint64(), C.c_uint64()
         gpu_check(self._g.kmpgpu_arena_info(self._ctx, C.byref(n), C.byref(b)), "kmpgpu_arena_info")

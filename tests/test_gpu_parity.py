@@ -547,6 +547,70 @@ def test_cli_openmp_task_streaming(fixture_counts, tokens, key, shards, batch):
     assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
 
 
+# ------------------------------------------------------------------------------------------------
+# on-device payload extraction (openmp_data.c:128-147 + packet_dumping.h:87-188 on the GPU)
+# ------------------------------------------------------------------------------------------------
+def _same_arena(gm, host_arena):
+    a, off, ln = gm.arena_download()
+    assert len(ln) == host_arena.n_pkts
+    assert ln.tolist() == host_arena.len.tolist() and off.tolist() == host_arena.off.tolist()
+    if host_arena.n_pkts:
+        end = int(off[-1]) + max(16, (int(ln[-1]) + 15) // 16 * 16)
+        assert np.array_equal(a[:end], host_arena.bytes[:end])          # payload bytes AND zero padding
+
+
+@pytest.mark.parametrize("key", FIXTURE_KEYS)
+def test_device_extraction_fixtures(gm, fixture_counts, tokens, key):
+    fx = fixture_counts["fixtures"][key]
+    path = os.path.join(DATA, fx["pcap"])
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(tokens)
+    assert gm.load_pcap_frames(path, fx["mode"]) == fx["payloads"]
+    assert gm.arena_info() == (fx["payloads"], fx["payload_bytes"])
+    _same_arena(gm, K.HostArena.from_pcap(path, fx["mode"]))
+    assert gm.scan()[0].tolist() == fx["counts"]
+
+
+def test_device_extraction_crafted_frames(gm, kat_extract, tmp_path):
+    """The reference extractors' known answers + random frames, through a pcap file, on the GPU."""
+    import struct
+    rng = random.Random(41)
+    frames = {"udp": [], "tcp": []}
+    for k in kat_extract:
+        frames[k["proto"]].append(bytes.fromhex(k["frame"])[: k["caplen"]])
+    for _ in range(3000):
+        n = rng.randrange(0, 130)
+        f = bytearray(rng.randrange(256) for _ in range(n))
+        if n > 23 and rng.random() < 0.6:
+            f[23] = 17
+        if n > 14 and rng.random() < 0.7:
+            f[14] = 0x40 | rng.choice([0, 4, 5, 5, 5, 6, 15])
+        if n > 46 and rng.random() < 0.5:
+            f[46] = rng.choice([0x40, 0x50, 0x50, 0x80, 0xF0])
+        frames["udp"].append(bytes(f))
+        frames["tcp"].append(bytes(f))
+    gm.set_patterns([b"ab"])
+    for proto in ("udp", "tcp"):
+        blob = struct.pack("<IHHiIII", 0xA1B2C3D4, 2, 4, 0, 0, 262144, 1)
+        for i, f in enumerate(frames[proto]):
+            blob += struct.pack("<IIII", i, 0, len(f), len(f)) + f
+        path = tmp_path / f"crafted_{proto}.pcap"
+        path.write_bytes(blob)
+        host = K.HostArena.from_pcap(str(path), proto)
+        assert gm.load_pcap_frames(str(path), proto) == host.n_pkts > 10
+        _same_arena(gm, host)
+
+
+def test_cli_device_extraction(fixture_counts, tokens):
+    env = dict(os.environ, KMPGPU_DEVICE_EXTRACT="1")
+    for key, prog, extra in (("big_udp.pcap:udp", "serial", []), ("udp_1000.pcap:tcp", "serial", []), ("big_udp.pcap:udp", "openmp_data", ["3"])):
+        fx = fixture_counts["fixtures"][key]
+        args = [os.path.join(_lib.BINDIR, prog), os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt")] + extra + [fx["mode"]]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
 def test_accumulate_option(gm, oracle):
     pats = [b"ab", b"abcab", b"c"]
     rng = random.Random(3)
