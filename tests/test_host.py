@@ -207,6 +207,23 @@ def test_synth_nuls_and_variable_lengths(oracle):
     oracle.count(a, off, ln, [b"XY"])
 
 
+# ---- the host C code under AddressSanitizer + UBSan (the reference itself fails ASan) ---
+@pytest.mark.parametrize("pcap,payloads", [("udp_1000.pcap", 321), ("tcp.pcap", 0), ("big_udp.pcap", 3358)])
+def test_host_library_under_sanitizers(tmp_path, pcap, payloads):
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "driver")
+    cmd = ["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+           "-fopenmp", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "host_sanitizer_driver.c"),
+           os.path.join(root, "multithreading_string_matching_amd", "csrc", "host", "kmphost.c"), "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe, os.path.join(DATA, pcap), os.path.join(DATA, "strings.txt"), str(payloads)], capture_output=True,
+                       text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and "sanitizer driver ok" in r.stdout, r.stderr[-2000:]
+
+
 # ---- command lines: what needs no GPU (serial.c:33-51,59-63,91-95) -------------------------------
 def _run(prog, *args):
     return subprocess.run([os.path.join(_lib.BINDIR, prog), *args], capture_output=True, text=True, timeout=120)
