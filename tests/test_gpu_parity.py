@@ -496,6 +496,43 @@ def test_full_size_property_1m(gm):
     gm.set_stream(None)
 
 
+def test_full_size_property_8m_shard(gm):
+    """BASELINE configs[3]: 64 M x 1500 B over 8 GPUs = 8 M packets (12 GB) per GPU.  One shard at
+    full size, generated with the packet ids of rank 5: count == planted (closed form), both streaming
+    kernels, and the two halves of the shard add up."""
+    import torch
+    needle = b"NEEDLE_16B_PATRN"
+    sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
+    n, first = 8_000_000, 5 * 8_000_000
+    stride = 1504
+    d_arena = torch.empty(n * stride + 64, dtype=torch.uint8, device="cuda")
+    d_off = torch.empty(n, dtype=torch.int64, device="cuda")
+    d_len = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gm.set_stream(None)
+    gm.fixed_index(d_off, d_len, 1500, 16)
+    gm.synth_fill(d_arena, d_off, d_len, sp, first_pkt_id=first)
+    gm.sync()
+    planted = K.synth_count_planted(sp, n, 1500, first_pkt_id=first)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns([needle])
+    gm.attach_arena(d_arena, d_off, d_len)
+    assert gm.arena_info() == (n, n * 1500)
+    for kernel in (KERNEL_AUTO, KERNEL_PACKED):
+        gm.set_option(OPT_KERNEL, kernel)
+        got, t = gm.scan()
+        assert int(got[0]) == planted
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+    half = n // 2
+    gm.attach_arena(d_arena, d_off[:half], d_len[:half])
+    a = int(gm.scan()[0][0])
+    gm.attach_arena(d_arena[half * stride:], d_off[:n - half], d_len[half:])       # offsets of a fixed index are shard-relative
+    b = int(gm.scan()[0][0])
+    assert a + b == planted
+    del d_arena, d_off, d_len
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------
 # the drop-in command lines
 # ------------------------------------------------------------------------------------------------
