@@ -78,6 +78,10 @@ typedef struct kmpgpu_match {
                                         overwriting it (batches of a streamed capture,
                                         openmp_task.c:172-175); kmpgpu_counts_reset() zeroes it */
 
+#define KMPGPU_OPT_NONTEMPORAL 100   /* 1 (default) = arena loads carry the non-temporal hint (every
+                                        byte is read once per pass; measured +10 % on MI355X), 0 =
+                                        default cache policy                                   */
+
 const char *kmpgpu_last_error(void);
 int  kmpgpu_device_count(void);                        /* >= 0, or KMPGPU_EHIP                */
 

@@ -560,8 +560,7 @@ __device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], uint4 v, u
     }
 }
 
-/* ABL (tuning only): 0 normal, 1 loads + waits only (no matching work), 2 matching work only (ring never refilled). */
-template <int DEPTH, bool MASKED, bool NT, int ABL = 0, bool EMIT = false>
+template <int DEPTH, bool MASKED, bool NT, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
                      uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
@@ -604,10 +603,8 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
         while (cb < range) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
-                if (ABL != 2) ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
-                if (ABL == 1) {
-                    asm volatile("" ::"v"(buf[s]));
-                } else if (cb < range) {
+                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (cb < range) {
                     const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
                     const u32x4    bn  = buf[(s + 1) % DEPTH];                /* next chunk (zeros past the range) */
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
@@ -636,7 +633,7 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                     p0 = min(p0, p0 - stride);               /* unsigned: subtracts stride iff p0 >= stride */
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ABL != 2) flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
+                flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
                 cb += KMP_CHUNK;
             }
         }
@@ -1271,11 +1268,7 @@ hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
     const Emitter em = emitter_of(a);
 #define KMP_FLAT_ARGS a.arena, a.n_pkts, a.uniform_stride, a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials, em
     if (a.emit_out)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, MASKED, true, 0, true>), grid, block, 0, st, KMP_FLAT_ARGS);
-    else if (a.ablate == 1 && DEPTH == 4 && !MASKED)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 1>), grid, block, 0, st, KMP_FLAT_ARGS);
-    else if (a.ablate == 2 && DEPTH == 4 && !MASKED)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, false, true, 2>), grid, block, 0, st, KMP_FLAT_ARGS);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_FLAT_ARGS);
     else if (a.nontemporal)
         hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_FLAT_ARGS);
     else

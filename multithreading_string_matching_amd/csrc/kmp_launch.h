@@ -32,7 +32,6 @@ struct kmp_scan_args {
     void                  *emit_out;
     unsigned long long    *emit_counter;
     unsigned long long     emit_cap;
-    int                    ablate;       /* tuning only: 1 memory-only, 2 compute-only variants of the flat kernel */
 };
 
 hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st);

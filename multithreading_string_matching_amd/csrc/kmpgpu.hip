@@ -97,7 +97,7 @@ struct kmpgpu_ctx {
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, ablate = 0, fused = 2 /* auto */, accumulate = 0;
+    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, fused = 2 /* auto */, accumulate = 0;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -203,7 +203,6 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     a.arena = c->d_arena; a.pkt_off = c->d_off; a.pkt_len = c->d_len; a.n_pkts = c->n_pkts;
     a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; a.mode = c->mode;
     a.nontemporal = c->nontemporal != 0;
-    a.ablate = c->ablate;
     if (emit) { a.emit_out = emit->out; a.emit_counter = emit->counter; a.emit_cap = emit->cap; }
     /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
     const uint64_t nwaves = (uint64_t)bx * KMP_BLOCK_WAVES;
@@ -385,9 +384,7 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
     case KMPGPU_OPT_KERNEL:
         if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "kernel selection must be 0, 1 or 2");
         c->kernel_sel = (int)value; return KMPGPU_OK;
-    case 101:                   /* undocumented, tuning only: ablation variants of the flat kernel (results are wrong) */
-        c->ablate = (int)value; return KMPGPU_OK;
-    case 100:                   /* undocumented: 0 = default cache policy loads, 1 = non-temporal */
+    case KMPGPU_OPT_NONTEMPORAL:
         c->nontemporal = value ? 1 : 0; return KMPGPU_OK;
     default:
         return fail(KMPGPU_EINVAL, "unknown option %d", key);
