@@ -836,7 +836,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
     __syncthreads();
     const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_tab + KMP_MULTI_BUCKET_W0);
-    const uint16_t *s_entry  = reinterpret_cast<const uint16_t *>(s_tab + KMP_MULTI_ENTRY_W0);
+    const uint32_t *s_entry  = s_tab + KMP_MULTI_ENTRY_W0;
 
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
@@ -905,8 +905,9 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
-                            const uint32_t word = s_tab[(d0 >> 5) & 0x7FFu];
-                            hm |= ((word >> (d0 & 31u)) & 1u) << (4 * q + a);
+                            const uint32_t bi = (d0 & 0xFFFFu) * 0x9E3Bu;                              /* KMP_MULTI_BIT: bank spreading */
+                            const uint32_t word = s_tab[(bi >> 5) & 0x7FFu];
+                            hm |= ((word >> (bi & 31u)) & 1u) << (4 * q + a);
                         }
                     }
                     if (ballot64(hm != 0u) != 0ull) {
@@ -929,21 +930,28 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                     const uint32_t o = vo0 + i;                         /* byte offset inside the chunk window */
                                     const uint32_t *src = win + (o >> 2);
                                     const uint32_t sa = o & 3u;
-                                    uint32_t r[6], T[5];
-#pragma unroll
-                                    for (int d = 0; d < 6; ++d) r[d] = src[d];
-#pragma unroll
-                                    for (int d = 0; d < 5; ++d) T[d] = __builtin_amdgcn_alignbyte(r[d + 1], r[d], sa);
-                                    uint32_t e = s_bucket[KMP_MULTI_HASH(T[0] & 0xFFFFu)];
+                                    const uint32_t r0 = src[0], r1 = src[1];
+                                    const uint32_t T0 = __builtin_amdgcn_alignbyte(r1, r0, sa);
+                                    const uint32_t b2 = (T0 >> 16) & 0xFFu;             /* third text byte: cheap pre-check per entry */
+                                    uint32_t e = s_bucket[KMP_MULTI_HASH(T0 & 0xFFFFu)];
                                     while (e != 0xFFFFu) {
                                         const uint32_t ent = s_entry[e];
-                                        const uint32_t uid = ent & 0x7FFFu;
-                                        const uint32_t *rec = s_tab + KMP_MULTI_REC_W0 + uid * KMP_MULTI_REC_WORDS;
-                                        uint32_t diff = 0u;
+                                        const uint32_t pb2 = (ent >> 8) & 0xFFu;
+                                        if (pb2 == 0u || pb2 == b2) {
+                                            /* rare: fetch the other 16 text bytes and the pattern record */
+                                            const uint32_t uid = ent & 0xFFu;
+                                            const uint32_t *rec = s_tab + KMP_MULTI_REC_W0 + uid * KMP_MULTI_REC_WORDS;
+                                            uint32_t diff = (T0 ^ rec[0]) & rec[5];
+                                            uint32_t prev = r1;
 #pragma unroll
-                                        for (int d = 0; d < 5; ++d) diff |= (T[d] ^ rec[d]) & rec[5 + d];
-                                        if (diff == 0u && (int32_t)(i + rec[10]) <= rem) atomicAdd(&s_cnt[uid], 1u);
-                                        e = (ent & 0x8000u) ? 0xFFFFu : e + 1u;
+                                            for (int d = 1; d < 5; ++d) {
+                                                const uint32_t nx = src[d + 1];
+                                                diff |= (__builtin_amdgcn_alignbyte(nx, prev, sa) ^ rec[d]) & rec[5 + d];
+                                                prev = nx;
+                                            }
+                                            if (diff == 0u && (int32_t)(i + rec[10]) <= rem) atomicAdd(&s_cnt[uid], 1u);
+                                        }
+                                        e = (ent & 0x80000000u) ? 0xFFFFu : e + 1u;
                                     }
                                 }
                             }

@@ -469,12 +469,13 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         const uint32_t U = (uint32_t)uniq.size();
         std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)U * KMP_MULTI_REC_WORDS, 0u);
         uint16_t *bucket = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_BUCKET_W0);
-        uint16_t *entry = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_ENTRY_W0);
+        uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
         std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
         for (uint32_t u = 0; u < U; u++) {
             const std::string &p = uniq[u];
             const uint32_t w16 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8);
-            tab[w16 >> 5] |= 1u << (w16 & 31u);
+            const uint32_t bi = KMP_MULTI_BIT(w16);
+            tab[bi >> 5] |= 1u << (bi & 31u);
             lists[KMP_MULTI_HASH(w16)].push_back(u);
             uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)u * KMP_MULTI_REC_WORDS;
             for (uint32_t b = 0; b < p.size(); b++) {
@@ -487,8 +488,11 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         for (uint32_t h = 0; h < KMP_MULTI_BUCKETS; h++) {
             if (lists[h].empty()) { bucket[h] = 0xFFFFu; continue; }
             bucket[h] = (uint16_t)pos;
-            for (size_t q = 0; q < lists[h].size(); q++)
-                entry[pos++] = (uint16_t)(lists[h][q] | (q + 1 == lists[h].size() ? 0x8000u : 0u));
+            for (size_t q = 0; q < lists[h].size(); q++) {
+                const std::string &p = uniq[lists[h][q]];
+                const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : 0u;      /* never 0x00 inside a pattern */
+                entry[pos++] = lists[h][q] | (third << 8) | (q + 1 == lists[h].size() ? 0x80000000u : 0u);
+            }
         }
         std::vector<uint32_t> rest(rest_l);
         rest.insert(rest.end(), rest_s.begin(), rest_s.end());
