@@ -237,6 +237,41 @@ def test_random_small_alphabet(gm, oracle, seed):
     check_payloads(gm, oracle, payloads, pats)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_all_kernels(gm, oracle, seed):
+    """Random alphabets, lengths (uniform or ragged), NUL densities and pattern sets (1..99 bytes, planted
+    and random, duplicates) through every kernel variant."""
+    rng = random.Random(1000 + seed)
+    alpha = rng.choice([b"ab", b"abc", b"abcdefgh", bytes(range(1, 256)), b"ht p:/\r\n"])
+    uniform = rng.random() < 0.4
+    Lmax = rng.choice([40, 300, 1500, 2600])
+    n = rng.choice([1, 7, 300, 900])
+    nul_p = rng.choice([0.0, 0.0, 0.002, 0.05])
+    L0 = rng.randrange(0, Lmax)
+    payloads = []
+    for _ in range(n):
+        L = L0 if uniform else rng.randrange(0, Lmax)
+        b = bytearray(rng.choice(alpha) for _ in range(L))
+        for i in range(L):
+            if nul_p and rng.random() < nul_p:
+                b[i] = 0
+        payloads.append(bytes(b))
+    pats = []
+    for _ in range(rng.choice([1, 3, 8, 20])):
+        m = rng.choice([1, 1, 2, 2, 3, 4, 4, 5, 7, 12, 16, 17, 20, 21, 40, 99])
+        src = rng.choice(payloads)
+        if len(src) >= m and rng.random() < 0.6:
+            s0 = rng.randrange(0, len(src) - m + 1)
+            p = src[s0:s0 + m]
+            if 0 in p:
+                p = bytes(rng.choice([x for x in alpha if x]) for _ in range(m))
+        else:
+            p = bytes(rng.choice([x for x in alpha if x]) for _ in range(m))
+        pats.append(p)
+    pats += pats[:2]                                   # duplicates are counted per occurrence in the file
+    check_payloads(gm, oracle, payloads, pats)
+
+
 def test_long_payloads(gm, oracle):
     rng = np.random.default_rng(9)
     payloads = []
@@ -553,6 +588,16 @@ def test_cli_serial_stdout(fixture_counts, tokens, key):
     r = _run("serial", os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt"), fx["mode"])
     assert r.returncode == 0, r.stderr
     assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+
+
+def test_cli_empty_pattern_file(tmp_path):
+    """No tokens: header + elapsed line only, exit 0 (the reference's loops simply do not run)."""
+    empty = tmp_path / "empty.txt"
+    empty.write_text(" \n\t\n")
+    for prog, extra in (("serial", []), ("openmp_data", ["2"]), ("openmp_task", ["2"])):
+        r = _run(prog, os.path.join(DATA, "udp_1000.pcap"), str(empty), *extra)
+        assert r.returncode == 0, r.stderr
+        assert _strip_elapsed(r.stdout) == K.format_report([], [])
 
 
 def test_cli_default_protocol_is_udp(fixture_counts, tokens):
