@@ -38,7 +38,9 @@ extern "C" {
 /* ---- pcap savefile reader ---------------------------------------------------------------
  * Replaces the three libpcap calls the reference makes: pcap_open_offline (serial.c:91,
  * openmp_data.c:94), pcap_next_ex (serial.c:115, openmp_data.c:107), pcap_close.  Classic pcap
- * only (magic a1b2c3d4 / a1b23c4d, either byte order); libpcap is not in this image. */
+ * (magic a1b2c3d4 / a1b23c4d, either byte order) and pcapng (enhanced, simple and obsolete packet
+ * blocks, either byte order, several sections) -- the two formats libpcap's pcap_open_offline reads;
+ * libpcap itself is not in this image. */
 typedef struct kmp_pcap kmp_pcap;
 #define KMP_PCAP_ERRBUF 256                       /* PCAP_ERRBUF_SIZE analogue, serial.c:26 */
 kmp_pcap *kmp_pcap_open(const char *path, char errbuf[KMP_PCAP_ERRBUF]);

@@ -20,11 +20,15 @@
 struct kmp_pcap {
     FILE    *fp;
     int      swap;          /* file byte order differs from the host's */
+    int      ng;            /* pcapng (libpcap's pcap_open_offline reads both formats) */
     uint32_t linktype;
     uint32_t snaplen;
     uint8_t *buf;
     size_t   cap;
 };
+
+#define PCAPNG_SHB 0x0A0D0D0Au
+#define PCAPNG_BOM 0x1A2B3C4Du
 
 static uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
@@ -42,9 +46,10 @@ kmp_pcap *kmp_pcap_open(const char *path, char errbuf[KMP_PCAP_ERRBUF])
         fclose(fp);
         return NULL;
     }
-    int swap;
+    int swap, ng = 0;
     if (h[0] == 0xA1B2C3D4u || h[0] == 0xA1B23C4Du) swap = 0;
     else if (bswap32(h[0]) == 0xA1B2C3D4u || bswap32(h[0]) == 0xA1B23C4Du) swap = 1;
+    else if (h[0] == PCAPNG_SHB && (h[2] == PCAPNG_BOM || bswap32(h[2]) == PCAPNG_BOM)) { ng = 1; swap = (h[2] != PCAPNG_BOM); }
     else {
         if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "unknown file format");
         fclose(fp);
@@ -54,13 +59,93 @@ kmp_pcap *kmp_pcap_open(const char *path, char errbuf[KMP_PCAP_ERRBUF])
     if (!p) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
     p->fp = fp;
     p->swap = swap;
-    p->snaplen = swap ? bswap32(h[4]) : h[4];
-    p->linktype = swap ? bswap32(h[5]) : h[5];
+    p->ng = ng;
+    if (ng) {
+        p->snaplen = 0; p->linktype = 1;
+        fseek(fp, 0, SEEK_SET);                     /* the block walker starts at the section header */
+    } else {
+        p->snaplen = swap ? bswap32(h[4]) : h[4];
+        p->linktype = swap ? bswap32(h[5]) : h[5];
+    }
     return p;
+}
+
+/* One pcapng block body in p->buf -> a packet?  Returns 1 and the packet, or 0 for other blocks. */
+static int pcapng_packet(kmp_pcap *p, uint32_t type, uint32_t body, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+{
+    const uint8_t *b = p->buf;
+    uint32_t w[5];
+    if (type == 6u && body >= 20u) {                 /* Enhanced Packet Block */
+        memcpy(w, b, 20);
+        const uint32_t cl = p->swap ? bswap32(w[3]) : w[3], ln = p->swap ? bswap32(w[4]) : w[4];
+        if (cl > body - 20u) return -1;
+        *caplen = cl; *len = ln; *data = b + 20;
+        return 1;
+    }
+    if (type == 2u && body >= 20u) {                 /* obsolete Packet Block */
+        memcpy(w, b, 20);
+        const uint32_t cl = p->swap ? bswap32(w[3]) : w[3], ln = p->swap ? bswap32(w[4]) : w[4];
+        if (cl > body - 20u) return -1;
+        *caplen = cl; *len = ln; *data = b + 20;
+        return 1;
+    }
+    if (type == 3u && body >= 4u) {                  /* Simple Packet Block */
+        memcpy(w, b, 4);
+        const uint32_t ln = p->swap ? bswap32(w[0]) : w[0];
+        uint32_t cl = ln;
+        if (p->snaplen && cl > p->snaplen) cl = p->snaplen;
+        if (cl > body - 4u) cl = body - 4u;
+        *caplen = cl; *len = ln; *data = b + 4;
+        return 1;
+    }
+    if (type == 1u && body >= 8u) {                  /* Interface Description Block: link type + snaplen of interface 0 */
+        uint16_t lt;
+        memcpy(&lt, b, 2);
+        memcpy(w, b + 4, 4);
+        if (p->snaplen == 0) {
+            p->linktype = p->swap ? (uint32_t)((lt >> 8) | ((lt & 0xFF) << 8)) : lt;
+            p->snaplen = p->swap ? bswap32(w[0]) : w[0];
+        }
+    }
+    return 0;
+}
+
+static int pcapng_next(kmp_pcap *p, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+{
+    for (;;) {
+        uint32_t hd[2];
+        size_t got = fread(hd, 1, sizeof hd, p->fp);
+        if (got == 0) return -2;
+        if (got != sizeof hd) return -1;
+        uint32_t type = hd[0], total = hd[1];
+        if (type == PCAPNG_SHB) {                    /* a new section may change the byte order */
+            uint32_t bom;
+            if (fread(&bom, 1, 4, p->fp) != 4) return -1;
+            if (bom == PCAPNG_BOM) p->swap = 0;
+            else if (bswap32(bom) == PCAPNG_BOM) p->swap = 1;
+            else return -1;
+            total = p->swap ? bswap32(total) : total;
+            if (total < 16u || (total & 3u) || fseek(p->fp, (long)total - 12, SEEK_CUR) != 0) return -1;
+            p->snaplen = 0;
+            continue;
+        }
+        if (p->swap) { type = bswap32(type); total = bswap32(total); }
+        if (total < 12u || (total & 3u) || total > (64u << 20)) return -1;
+        const uint32_t body = total - 12u;
+        if (body + 4u > p->cap) {
+            uint8_t *nb = (uint8_t *)realloc(p->buf, (size_t)body + 4096u);
+            if (!nb) return -1;
+            p->buf = nb; p->cap = (size_t)body + 4096u;
+        }
+        if (fread(p->buf, 1, (size_t)body + 4u, p->fp) != (size_t)body + 4u) return -1;    /* body + trailing length */
+        const int r = pcapng_packet(p, type, body, caplen, len, data);
+        if (r != 0) return r;
+    }
 }
 
 int kmp_pcap_next(kmp_pcap *p, uint32_t *caplen, uint32_t *len, const uint8_t **data)
 {
+    if (p->ng) return pcapng_next(p, caplen, len, data);
     uint32_t r[4];
     size_t got = fread(r, 1, sizeof r, p->fp);
     if (got == 0) return -2;                    /* clean end of file */
@@ -343,13 +428,49 @@ int kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn fr
     memset(out->bytes + sz, 0, 64);
     uint32_t magic;
     memcpy(&magic, out->bytes, 4);
-    int swap;
+    int swap, ng = 0;
+    uint32_t bom = 0;
+    memcpy(&bom, out->bytes + 8, 4);
     if (magic == 0xA1B2C3D4u || magic == 0xA1B23C4Du) swap = 0;
     else if (bswap32(magic) == 0xA1B2C3D4u || bswap32(magic) == 0xA1B23C4Du) swap = 1;
+    else if (magic == PCAPNG_SHB && (bom == PCAPNG_BOM || bswap32(bom) == PCAPNG_BOM)) { ng = 1; swap = 0; }
     else { kmp_frames_free(out); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "unknown file format"); return KMPHOST_EFORMAT; }
     for (int pass = 0; pass < 2; pass++) {
-        uint64_t pos = 24, n = 0;
-        while (pos + 16 <= (uint64_t)sz) {
+        uint64_t pos = ng ? 0 : 24, n = 0;
+        uint32_t snap = 0;
+        while (ng && pos + 12 <= (uint64_t)sz) {                               /* pcapng: walk the blocks */
+            uint32_t type, total, w[5];
+            memcpy(&type, out->bytes + pos, 4);
+            memcpy(&total, out->bytes + pos + 4, 4);
+            if (type == PCAPNG_SHB) {
+                memcpy(&bom, out->bytes + pos + 8, 4);
+                if (bom == PCAPNG_BOM) swap = 0; else if (bswap32(bom) == PCAPNG_BOM) swap = 1; else break;
+                snap = 0;
+            }
+            if (swap) { type = bswap32(type); total = bswap32(total); }
+            if (total < 12u || (total & 3u) || pos + total > (uint64_t)sz) break;
+            const uint32_t body = total - 12u;
+            const uint8_t *b = out->bytes + pos + 8;
+            uint64_t doff = 0; uint32_t cl = 0; int pkt = 0;
+            if ((type == 6u || type == 2u) && body >= 20u) {
+                memcpy(w, b, 20);
+                cl = swap ? bswap32(w[3]) : w[3];
+                if (cl > body - 20u) break;
+                doff = pos + 8 + 20; pkt = 1;
+            } else if (type == 3u && body >= 4u) {
+                memcpy(w, b, 4);
+                cl = swap ? bswap32(w[0]) : w[0];
+                if (snap && cl > snap) cl = snap;
+                if (cl > body - 4u) cl = body - 4u;
+                doff = pos + 8 + 4; pkt = 1;
+            } else if (type == 1u && body >= 8u && snap == 0) {
+                memcpy(w, b + 4, 4);
+                snap = swap ? bswap32(w[0]) : w[0];
+            }
+            if (pkt) { if (pass) { out->off[n] = doff; out->caplen[n] = cl; } n++; }
+            pos += total;
+        }
+        while (!ng && pos + 16 <= (uint64_t)sz) {
             uint32_t cl;
             memcpy(&cl, out->bytes + pos + 8, 4);
             if (swap) cl = bswap32(cl);

@@ -59,6 +59,57 @@ def test_pcap_variants(tmp_path):
         list(K.read_pcap(str(tmp_path / "missing.pcap")))
 
 
+def _pcapng_bytes(frames, endian="<", simple=False, snaplen=262144):
+    """pcapng: SHB, IDB, one unknown block, then one packet block per frame (EPB with an option, or SPB)."""
+    def block(btype, body):
+        body += b"\0" * (-len(body) % 4)
+        total = len(body) + 12
+        return struct.pack(endian + "II", btype, total) + body + struct.pack(endian + "I", total)
+    out = block(0x0A0D0D0A, struct.pack(endian + "IHHq", 0x1A2B3C4D, 1, 0, -1))
+    out += block(1, struct.pack(endian + "HHI", 1, 0, snaplen) + struct.pack(endian + "HH", 2, 4) + b"eth0" + struct.pack(endian + "HH", 0, 0))
+    out += block(0x0BAD, b"some block a reader must skip")
+    for i, f in enumerate(frames):
+        if simple:
+            out += block(3, struct.pack(endian + "I", len(f)) + f)
+        else:
+            opts = struct.pack(endian + "HH", 1, 3) + b"hey\0" + struct.pack(endian + "HH", 0, 0)
+            pad = b"\0" * (-len(f) % 4)
+            out += block(6, struct.pack(endian + "IIIII", 0, 0, i, len(f), len(f)) + f + pad + opts)
+    return out
+
+
+@pytest.mark.parametrize("name", ["udp.pcap", "udp_1000.pcap", "tcp.pcap"])
+def test_pcapng_reader(tmp_path, name):
+    """libpcap reads pcapng too; the same frames must come out of a pcapng rendering of a fixture, through
+    the record reader, the arena builder and the frame walker of the device-extraction route."""
+    import ctypes as C
+    frames = [f for _, _, f in read_pcap_py(os.path.join(DATA, name))]
+    for endian in "<>":
+        for simple in (False, True):
+            p = tmp_path / f"{name}.{endian == '<'}.{simple}.pcapng"
+            p.write_bytes(_pcapng_bytes(frames, endian, simple))
+            got = list(K.read_pcap(str(p)))
+            assert [g[2] for g in got] == frames and all(g[0] == len(g[2]) for g in got)
+            a = K.HostArena.from_pcap(str(p), "udp")
+            b = K.HostArena.from_pcap(os.path.join(DATA, name), "udp")
+            assert a.n_pkts == b.n_pkts and a.len.tolist() == b.len.tolist() and np.array_equal(a.bytes, b.bytes)
+            L = _lib.host_lib()
+            fr = _lib.Frames()
+            err = C.create_string_buffer(256)
+            assert L.kmp_frames_from_pcap(str(p).encode(), None, None, C.byref(fr), err) == 0
+            assert fr.n == len(frames)
+            raw = p.read_bytes()
+            for i in (0, len(frames) // 2, len(frames) - 1):
+                assert raw[fr.off[i]:fr.off[i] + fr.caplen[i]] == frames[i]
+            L.kmp_frames_free(C.byref(fr))
+    snap = tmp_path / "snap.pcapng"                       # simple packet blocks are cut at the interface's snaplen
+    snap.write_bytes(_pcapng_bytes(frames[:5], "<", True, snaplen=40))
+    assert [g[0] for g in K.read_pcap(str(snap))] == [min(40, len(f)) for f in frames[:5]]
+    trunc = tmp_path / "trunc.pcapng"
+    trunc.write_bytes(_pcapng_bytes(frames[:5])[:-9])      # a truncated last block ends the loop (serial.c:115)
+    assert [g[2] for g in K.read_pcap(str(trunc))] == frames[:4]
+
+
 # ---- extraction (packet_dumping.h:87-188) ----------------------------------------------------
 def test_extract_known_answers(kat_extract):
     for k in kat_extract:
@@ -219,9 +270,12 @@ def test_host_library_under_sanitizers(tmp_path, pcap, payloads):
            "-fopenmp", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "host_sanitizer_driver.c"),
            os.path.join(root, "multithreading_string_matching_amd", "csrc", "host", "kmphost.c"), "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, timeout=300)
-    r = subprocess.run([exe, os.path.join(DATA, pcap), os.path.join(DATA, "strings.txt"), str(payloads)], capture_output=True,
-                       text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
-    assert r.returncode == 0 and "sanitizer driver ok" in r.stdout, r.stderr[-2000:]
+    ng = tmp_path / "as.pcapng"                           # the same capture as pcapng (big-endian, enhanced packet blocks)
+    ng.write_bytes(_pcapng_bytes([f for _, _, f in read_pcap_py(os.path.join(DATA, pcap))], ">"))
+    for path in (os.path.join(DATA, pcap), str(ng)):
+        r = subprocess.run([exe, path, os.path.join(DATA, "strings.txt"), str(payloads)], capture_output=True,
+                           text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+        assert r.returncode == 0 and "sanitizer driver ok" in r.stdout, r.stderr[-2000:]
 
 
 # ---- command lines: what needs no GPU (serial.c:33-51,59-63,91-95) -------------------------------
