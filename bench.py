@@ -202,8 +202,16 @@ def main() -> None:
             if int(counts[0]) != planted:
                 raise SystemExit(f"oracle count {int(counts[0])} != GPU/planted {planted}")
             best = dt if best is None else min(best, dt)
+        # one-thread figure (the serial.c loop, serial.c:153-155) on the first 100 000 packets
+        n1 = min(n, 100_000)
+        t1 = time.perf_counter()
+        c1, _ = o.count(host, off[:n1], ln[:n1], [NEEDLE], threads=0)
+        t1 = time.perf_counter() - t1
+        if int(c1[0]) != K.synth_count_planted(sp, n1, PAYLOAD_LEN, first_pkt_id=first_id):
+            raise SystemExit("oracle serial count differs from the planted count")
         cpu = {
             "value": round(payload_bytes / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "serial_1thread_GBps": round(n1 * PAYLOAD_LEN / t1 / 1e9, 3),
             "sample": f"the full per-GPU workload ({n} x {PAYLOAD_LEN} B, 1 pattern), best of {max(1, args.cpu_reps)} passes, "
                       f"openmp_data.c:126-178 bracket, {best:.3f} s per pass",
             "matches_per_s": round(planted / best, 1),

@@ -138,6 +138,8 @@ int  kmpgpu_scan_enqueue(kmpgpu_ctx *ctx, void *d_counts_out);
 void *kmpgpu_counts_device(kmpgpu_ctx *ctx);
 /* Zero the context's own counts buffer (asynchronous, on the context's stream). */
 int  kmpgpu_counts_reset(kmpgpu_ctx *ctx);
+/* Timing of the context's last kmpgpu_load_arena / kmpgpu_load_frames / kmpgpu_scan. */
+int  kmpgpu_last_timing(kmpgpu_ctx *ctx, kmpgpu_timing *t);
 /* Wait for the context's stream and copy its own counts buffer to the host (uint64_t[n_pat]). */
 int  kmpgpu_counts_read(kmpgpu_ctx *ctx, uint64_t *counts_out);
 int  kmpgpu_sync(kmpgpu_ctx *ctx);

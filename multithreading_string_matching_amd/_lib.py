@@ -129,6 +129,7 @@ GPU_API = {
     "kmpgpu_scan_enqueue": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kmpgpu_counts_device": (C.c_void_p, [C.c_void_p]),
     "kmpgpu_counts_reset": (C.c_int, [C.c_void_p]),
+    "kmpgpu_last_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "kmpgpu_counts_read": (C.c_int, [C.c_void_p, u64p]),
     "kmpgpu_sync": (C.c_int, [C.c_void_p]),
     "kmpgpu_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),

@@ -174,6 +174,7 @@ int main(int argc, char *argv[])
             /* slots are contiguous and at least 16 bytes each, so [b0, b1) holds the whole shard */
             if (kmpgpu_load_arena(ctx[r], arena.bytes + b0, b1 - b0, reb + lo, arena.len + lo, cnt))
                 die_gpu("kmpgpu_load_arena");
+            { kmpgpu_timing lt; if (kmpgpu_last_timing(ctx[r], &lt) == 0) h2d_ms += lt.h2d_ms; }
             lo = hi;
         }
         const char *off_path = getenv("KMPGPU_OFFSETS_FILE");
@@ -183,12 +184,20 @@ int main(int argc, char *argv[])
             if (!off_fp) { perror("KMPGPU_OFFSETS_FILE"); exit(1); }
         }
         uint64_t shard_lo = 0;
+        const double t_scan0 = now_s();
+        /* every shard's pass is enqueued before any result is read, so the GPUs work side by side
+         * (mpi_dumping.c:198-202: all ranks count, then one reduce) */
+        for (int r = 0; r < shards; r++)
+            if (kmpgpu_scan_enqueue(ctx[r], NULL)) die_gpu("kmpgpu_scan_enqueue");
         for (int r = 0; r < shards; r++) {
-            kmpgpu_timing t;
+            if (kmpgpu_counts_read(ctx[r], part)) die_gpu("kmpgpu_counts_read");
+            for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];     /* mpi_dumping.c:202 MPI_SUM */
+        }
+        kernel_ms = (now_s() - t_scan0) * 1e3;                              /* wall time of the concurrent passes (mpi_dumping.c:206 MPI_MAX) */
+        for (int r = 0; r < shards; r++) {
             if (off_fp) {
-                /* counts first (cheap), then exactly as many match records as were counted */
-                if (kmpgpu_scan(ctx[r], part, &t)) die_gpu("kmpgpu_scan");
                 uint64_t total = 0, found = 0;
+                if (kmpgpu_counts_read(ctx[r], part)) die_gpu("kmpgpu_counts_read");
                 for (uint32_t i = 0; i < pats.n; i++) total += part[i];
                 kmpgpu_match *mm = (kmpgpu_match *)malloc(sizeof *mm * (size_t)(total ? total : 1));
                 if (!mm || kmpgpu_scan_offsets(ctx[r], mm, total, &found, NULL)) die_gpu("kmpgpu_scan_offsets");
@@ -197,10 +206,6 @@ int main(int argc, char *argv[])
                 free(mm);
             }
             shard_lo += arena.n_pkts / (uint64_t)shards + (r == 0 ? arena.n_pkts % (uint64_t)shards : 0);
-            if (kmpgpu_scan(ctx[r], part, &t)) die_gpu("kmpgpu_scan");
-            for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];     /* mpi_dumping.c:202 MPI_SUM */
-            if (t.kernel_ms > kernel_ms) kernel_ms = t.kernel_ms;           /* mpi_dumping.c:206 MPI_MAX */
-            h2d_ms += t.h2d_ms;
         }
         if (off_fp) fclose(off_fp);
         for (int r = 0; r < shards; r++) kmpgpu_destroy(ctx[r]);

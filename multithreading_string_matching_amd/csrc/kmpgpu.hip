@@ -714,6 +714,13 @@ int kmpgpu_counts_reset(kmpgpu_ctx *c)
     return KMPGPU_OK;
 }
 
+int kmpgpu_last_timing(kmpgpu_ctx *c, kmpgpu_timing *t)
+{
+    if (!c || !t) return fail(KMPGPU_EINVAL, "kmpgpu_last_timing: NULL argument");
+    *t = c->last;
+    return KMPGPU_OK;
+}
+
 int kmpgpu_counts_read(kmpgpu_ctx *c, uint64_t *counts_out)
 {
     if (!c || (!counts_out && c->n_pat)) return fail(KMPGPU_EINVAL, "kmpgpu_counts_read: NULL argument");
