@@ -206,7 +206,14 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     if (emit) { a.emit_out = emit->out; a.emit_counter = emit->counter; a.emit_cap = emit->cap; }
     /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
     const uint64_t nwaves = (uint64_t)bx * KMP_BLOCK_WAVES;
-    const uint64_t ppw = (c->n_pkts + nwaves - 1) / nwaves;
+    uint64_t ppw = (c->n_pkts + nwaves - 1) / nwaves;
+    if (c->uniform && c->uni_stride) {
+        /* start every wavefront's range on a 128-byte line so that neighbouring ranges share no cache line */
+        uint64_t g = c->uni_stride, r = 128;
+        while (r) { const uint64_t t = g % r; g = r; r = t; }      /* gcd(stride, 128) */
+        const uint64_t q = 128 / g;
+        ppw = (ppw + q - 1) / q * q;
+    }
     const bool flat = use_flat(c) && ppw * c->uni_stride < (1ull << 31);
     if (flat) {
         a.arena = c->d_arena + c->uni_off0;

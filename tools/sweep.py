@@ -35,7 +35,7 @@ def main():
     needle = b"NEEDLE_16B_PATRN"
     sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
     m = GpuMatcher(0)
-        stride = (L + args.align - 1) // args.align * args.align
+    stride = (L + args.align - 1) // args.align * args.align
     if args.zipf:
         rng = np.random.default_rng(4)
         ranks = np.arange(1, 9000 - 64 + 2)
