@@ -65,8 +65,10 @@ def host_cores() -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=400, help="untimed passes before the warm-up so that the GPU's clocks have "
+                    "settled (a 250 us kernel needs ~100 ms of load to leave the DVFS transient; profiles/r01_sustained.txt)")
     ap.add_argument("--packets-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--depth", type=int, default=0, help="chunk loads in flight per wavefront (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
@@ -161,6 +163,9 @@ def main() -> None:
                 w.wait()
                 works[s] = None
 
+    for i in range(args.settle):               # device settle-in, not part of W or K
+        m.scan_enqueue(ring[0])
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     drain()
