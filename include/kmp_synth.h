@@ -1,6 +1,6 @@
 /*
  * kmp_synth.h -- counter-based synthetic payload generator, shared verbatim by the host C code
- * (csrc/host/kmphost.c) and the HIP fill kernel (csrc/kmp_kernels.hip), so that any shard of the
+ * (csrc/host/kmphost.c) and the HIP fill kernel (csrc/kmp_prep.hip), so that any shard of the
  * benchmark arena can be produced on the host or on the device with identical bytes.
  *
  * Not in the reference (it ships pcap files only); this is SURVEY.md section 8(d) input "S1/S2":

@@ -1,5 +1,5 @@
 /*
- * kmp_device.h -- layouts shared by the HIP kernels (kmp_kernels.hip) and the C-ABI host code
+ * kmp_device.h -- layouts shared by the HIP kernels (kmp_scan_*.hip / kmp_prep.hip) and the C-ABI host code
  * (kmpgpu.hip).  gfx950 only.
  */
 #ifndef KMP_DEVICE_H

@@ -1,4 +1,4 @@
-/* kmp_launch.h -- launch entry points of kmp_kernels.hip, used by the C-ABI layer (kmpgpu.hip). */
+/* kmp_launch.h -- launch entry points of kmp_scan_*.hip / kmp_prep.hip, used by the C-ABI layer (kmpgpu.hip). */
 #ifndef KMP_LAUNCH_H
 #define KMP_LAUNCH_H
 

@@ -1,0 +1,199 @@
+/*
+ * kmp_scan_multi.hip -- fused multi-pattern pass, gfx950.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kmp_device.h"
+#include "kmp_launch.h"
+#include "kmp_dev_common.h"
+
+namespace {
+
+/* ================================================================================================
+ * Fused multi-pattern pass: every pattern of 2..20 bytes in ONE read of a packed
+ * arena -- the reference re-reads every payload once per pattern (serial.c:154, openmp_data.c:163).
+ *
+ * Same streaming skeleton as kmp_scan_packed_kernel (buffer-load ring, packet-start bitmap, byte-
+ * balanced plan).  Per chunk:
+ *   - rem = payload bytes left from the lane's first byte (uniform loop over the packet starts of the
+ *     chunk; lengths come by scalar loads, offsets are implied by the bitmap because the arena is packed);
+ *   - level 1: the 2-byte window at each of the 16 start offsets indexes a 64 Kbit LDS bitmap "some
+ *     pattern starts with these two bytes" -> 16-bit hit mask per lane;
+ *   - level 2, per start offset that has a hit in some lane: hash the 2 bytes to a bucket, walk the
+ *     bucket's short list of patterns, compare up to 20 bytes dword-wise with byte masks (text from
+ *     registers, pattern records from LDS), check window-in-payload and the strlen() rule, and bump
+ *     the pattern's counter in LDS.  Counters go to partials[unique pattern][block] at the end.
+ * ============================================================================================== */
+template <int DEPTH, bool NT>
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
+                      const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
+                      const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,
+                      unsigned long long *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];    /* tables, counters, then one chunk window per wavefront */
+    uint32_t *s_cnt = s_tab + table_words;
+    uint32_t *s_win = s_tab + ((table_words + n_unique + 3u) & ~3u);
+    for (uint32_t i = threadIdx.x; i < table_words; i += KMP_BLOCK_THREADS) s_tab[i] = tables[i];
+    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
+    __syncthreads();
+    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_tab + KMP_MULTI_BUCKET_W0);
+    const uint32_t *s_entry  = s_tab + KMP_MULTI_ENTRY_W0;
+
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint32_t wave = sgpr(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+    const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
+    const uint64_t off0 = plan[gw].off;
+    const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;
+
+    if (range) {
+        const i32x4    rsrc = make_rsrc(arena + off0, range);
+        const uint32_t vo0 = lane * KMP_LANE_BYTES;
+        const uint64_t b0 = off0 >> 4;
+        const unsigned long long *bw = bitmap + (b0 >> 6);
+        const uint32_t sh = (uint32_t)(b0 & 63ull);
+
+        u32x4 buf[DEPTH];
+        unsigned long long hiw[DEPTH];
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+            hiw[s] = bw[s + 1];
+        }
+        unsigned long long low = bw[0];
+        uint64_t kcur = k0 - 1ull;           /* last packet that has started                                   */
+        int32_t  remc = 0;                   /* payload bytes of that packet left at the chunk's first byte     */
+        bool     dead = false;
+        uint32_t cb = 0u, j = 0u;
+
+        while (cb < range) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (cb < range) {
+                    const uint4 v  = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    const u32x4 bn = buf[(s + 1) % DEPTH];
+                    const unsigned long long hi = hiw[s];
+                    uint64_t st = sh ? ((low >> sh) | (hi << (64u - sh))) : low;
+                    low = hi;
+                    const uint32_t left = range - cb;
+                    if (left < KMP_CHUNK) st &= (1ull << (left >> 4)) - 1ull;        /* bits past the range belong to the next wavefront */
+
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
+
+                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
+                    const uint64_t zl = ballot64(zm != 0u);
+                    const bool dead_in = dead;
+                    if (zl == 0ull) { if (st != 0ull) dead = false; }
+                    else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
+
+                    /* payload bytes left from this lane's first byte (<= 0: slot padding) */
+                    int32_t rem = remc - (int32_t)vo0;
+                    int32_t remn = remc - (int32_t)KMP_CHUNK;
+                    for (uint64_t sb = st; sb != 0ull; sb &= sb - 1ull) {
+                        const uint32_t sl = (uint32_t)__builtin_ctzll(sb);
+                        ++kcur;
+                        const int32_t top = (int32_t)pkt_len[kcur] + (int32_t)(sl * KMP_LANE_BYTES);
+                        if (lane >= sl) rem = top - (int32_t)vo0;
+                        remn = top - (int32_t)KMP_CHUNK;
+                    }
+                    remc = remn;
+
+                    /* level 1: which start offsets begin with the first two bytes of some pattern? */
+                    uint32_t hm = 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
+                            const uint32_t bi = (d0 & 0xFFFFu) * 0x9E3Bu;                              /* KMP_MULTI_BIT: bank spreading */
+                            const uint32_t word = s_tab[(bi >> 5) & 0x7FFu];
+                            hm |= ((word >> (bi & 31u)) & 1u) << (4 * q + a);
+                        }
+                    }
+                    if (ballot64(hm != 0u) != 0ull) {
+                        /* keep only the start offsets that can count: no 0x00 before them (strlen rule) and at
+                         * least the shortest pattern still inside the payload */
+                        int32_t lim = min(15, rem - (int32_t)KMP_MULTI_MIN_LEN);
+                        if (zl != 0ull || dead_in) lim = min(lim, nul_limit(15, w, zl, st, dead_in, lane));
+                        hm = (lim < 0) ? 0u : (hm & ((2u << lim) - 1u));
+                        if (ballot64(hm != 0u) != 0ull) {
+                            /* level 2.  Stage the chunk + 32 bytes of halo in this wavefront's LDS window so that a
+                             * lane can fetch the 20 bytes behind ANY of its start offsets, then let every lane walk
+                             * its own hits: iterations = the largest hit count of a lane, not 16. */
+                            uint32_t *win = s_win + wave * (KMP_CHUNK / 4u + 8u);
+                            *reinterpret_cast<uint4 *>(win + lane * 4u) = v;
+                            if (lane < 2u) *reinterpret_cast<uint4 *>(win + KMP_CHUNK / 4u + lane * 4u) = make_uint4(bn.x, bn.y, bn.z, bn.w);
+                            while (ballot64(hm != 0u) != 0ull) {
+                                if (hm != 0u) {
+                                    const uint32_t i = (uint32_t)__builtin_ctz(hm);
+                                    hm &= hm - 1u;
+                                    const uint32_t o = vo0 + i;                         /* byte offset inside the chunk window */
+                                    const uint32_t *src = win + (o >> 2);
+                                    const uint32_t sa = o & 3u;
+                                    const uint32_t r0 = src[0], r1 = src[1];
+                                    const uint32_t T0 = __builtin_amdgcn_alignbyte(r1, r0, sa);
+                                    const uint32_t b2 = (T0 >> 16) & 0xFFu;             /* third text byte: cheap pre-check per entry */
+                                    uint32_t e = s_bucket[KMP_MULTI_HASH(T0 & 0xFFFFu)];
+                                    while (e != 0xFFFFu) {
+                                        const uint32_t ent = s_entry[e];
+                                        const uint32_t pb2 = (ent >> 8) & 0xFFu;
+                                        if (pb2 == 0u || pb2 == b2) {
+                                            /* rare: fetch the other 16 text bytes and the pattern record */
+                                            const uint32_t uid = ent & 0xFFu;
+                                            const uint32_t *rec = s_tab + KMP_MULTI_REC_W0 + uid * KMP_MULTI_REC_WORDS;
+                                            uint32_t diff = (T0 ^ rec[0]) & rec[5];
+                                            uint32_t prev = r1;
+#pragma unroll
+                                            for (int d = 1; d < 5; ++d) {
+                                                const uint32_t nx = src[d + 1];
+                                                diff |= (__builtin_amdgcn_alignbyte(nx, prev, sa) ^ rec[d]) & rec[5 + d];
+                                                prev = nx;
+                                            }
+                                            if (diff == 0u && (int32_t)(i + rec[10]) <= rem) atomicAdd(&s_cnt[uid], 1u);
+                                        }
+                                        e = (ent & 0x80000000u) ? 0xFFFFu : e + 1u;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
+                hiw[s] = bw[j + (uint32_t)DEPTH + 1u];
+                cb += KMP_CHUNK;
+                ++j;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+    }
+
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS)
+        partials[(uint64_t)i * gridDim.x + blockIdx.x] = s_cnt[i];
+}
+
+}  // namespace
+
+/* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
+hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
+                                 hipStream_t st)
+{
+    if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
+    const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
+    const size_t lds = ((size_t)((table_words + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
+    if (a.nontemporal)
+        hipLaunchKernelGGL((kmp_scan_multi_kernel<4, true>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, a.arena, a.pkt_len,
+                           a.bitmap, plan, tables, table_words, n_unique, a.partials);
+    else
+        hipLaunchKernelGGL((kmp_scan_multi_kernel<4, false>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, a.arena, a.pkt_len,
+                           a.bitmap, plan, tables, table_words, n_unique, a.partials);
+    return hipGetLastError();
+}
+

@@ -1,0 +1,397 @@
+/*
+ * kmp_scan_stream.hip -- the hot path on gfx950 (MI355X / CDNA4): per-pattern match counts over a
+ * payload arena.  Replaces the reference loop serial.c:153-155 (= openmp_data.c:157-175) and its
+ * kernel function kmp_matcher (serial.c:190-215).  Hand-written for 64-lane wavefronts; no MFMA
+ * (byte scan, HBM-bound).
+ *
+ * Shape of the scan kernel
+ *   - one packet per wavefront at a time; a persistent grid strides over the packets;
+ *   - a packet is read in 1 KiB chunks: one global_load_dwordx4 per lane, perfectly coalesced,
+ *     DEPTH chunk loads in flight per wavefront (register ring), packets pipelined back to back;
+ *   - the pattern and its KMP failure table are staged in LDS once per block;
+ *   - per chunk, every lane tests its 16 start offsets with a 4-byte SWAR compare against the
+ *     pattern's first dword (halo dword from the next lane by DPP wave_shl:1) and looks for a
+ *     0x00 byte with the has-zero trick; both results are wave-reduced with ballots;
+ *   - the common case (no candidate in the chunk) ends there.  Otherwise the candidates are
+ *     confirmed: patterns of <= 4 bytes are already exact; longer ones run the KMP automaton
+ *     (LDS pattern + failure table) over the lane's 16 + m - 1 bytes, all in registers, the halo
+ *     arriving by repeated wave_shl:1 shifts;
+ *   - the reference's strlen() rule (serial.c:191): a start offset s counts only if
+ *     s + m <= E, E = min(len, first 0x00).  A chunk that holds the first NUL ends the packet.
+ *   - counts: per-lane -> wave -> block, one partial per (block, pattern), summed by
+ *     kmp_reduce_kernel (no atomics, deterministic).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kmp_device.h"
+#include "kmp_launch.h"
+#include "kmp_dev_common.h"
+
+namespace {
+
+/* ================================================================================================
+ * Uniform-stride arenas (every payload the same length, slots back to back): flat streaming.
+ *
+ * Each wavefront owns a CONTIGUOUS run of packets, i.e. one contiguous byte range of the arena,
+ * and streams it in 1 KiB chunks irrespective of packet boundaries: every lane always holds 16
+ * useful bytes, consecutive chunk loads are consecutive addresses, and there is no per-packet
+ * scalar work at all.  Because slots are 16-byte aligned a lane's 16 bytes belong to exactly one
+ * packet; the lane tracks p0 = offset of its first byte inside that packet's slot with one
+ * add + min per chunk.  Still one packet per wavefront at a time: the packets of a range are
+ * scanned in order by the same wavefront, so the "first 0x00 ends the text" rule (serial.c:191)
+ * is wave-local state (dead: the packet entering the chunk already had a NUL).
+ *
+ * A start offset s (lane position i, s = p0 + i) counts iff
+ *     s + m <= L                       window inside the payload                  (serial.c:193,198)
+ *     no 0x00 in the packet before s   strlen() stopped earlier otherwise         (serial.c:191)
+ *     text[s : s+m] == pattern         (a NUL inside the window fails here: patterns are NUL-free)
+ * ============================================================================================== */
+
+
+template <int DEPTH, bool MASKED, bool NT, bool EMIT = false>
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
+                     uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
+                     const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
+{
+    __shared__ kmp_pattern_dev s_pat;
+    __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
+
+    const uint32_t pid = pat_ids[blockIdx.y];
+    const kmp_pattern_dev *gp = patterns + pid;
+    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
+        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
+    __syncthreads();
+
+    const PatConst pc = load_pat_const(gp);
+    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint32_t wave = sgpr(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+    if (EMIT) em.pattern = pid;
+    /* this wavefront's packets [k0, k1) = bytes [0, range) behind base */
+    const uint64_t k0 = gw * pkts_per_wave;
+    const uint64_t k1 = min(n_pkts, k0 + pkts_per_wave);
+    const uint32_t range = (k0 < n_pkts) ? (uint32_t)(k1 - k0) * stride : 0u;      /* host guarantees < 2^31 */
+    const uint8_t *base = arena + ((k0 < n_pkts) ? k0 * (uint64_t)stride : 0ull);
+    const uint32_t step_mod = KMP_CHUNK % stride;                                    /* p0 advance per chunk (mod stride) */
+
+    uint32_t cnt = 0u;
+    if (range) {
+        const i32x4    rsrc = make_rsrc(base, range);
+        const uint32_t vo0 = lane * KMP_LANE_BYTES;
+        u32x4 buf[DEPTH];
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+
+        uint32_t p0 = vo0 % stride;          /* offset of this lane's first byte inside its packet's slot */
+        bool     dead = false;               /* the packet that enters the chunk already had a 0x00      */
+        uint32_t cb = 0u;                    /* byte offset of the chunk being consumed                   */
+
+        while (cb < range) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (cb < range) {
+                    const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    const u32x4    bn  = buf[(s + 1) % DEPTH];                /* next chunk (zeros past the range) */
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
+
+                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
+                    const uint32_t fm = filter_min<MASKED>(w, first, mask);
+                    const uint64_t zl = ballot64(zm != 0u);                   /* lanes holding a 0x00           */
+                    const uint64_t st = ballot64(p0 == 0u);                   /* lanes where a packet starts    */
+                    const uint64_t cl = ballot64(fm == 0u);                   /* lanes with a candidate         */
+                    const bool dead_in = dead;
+                    /* carry for the next chunk: is there a 0x00 at or after the last packet start of this chunk? */
+                    if (zl == 0ull) { if (st != 0ull) dead = false; }
+                    else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
+
+                    if (cl != 0ull) {
+                        /* rare path.  maxi = largest start index (0..15) of this lane that still counts:
+                         * window inside the payload, no 0x00 before it, lane has a candidate at all. */
+                        int32_t maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
+                        if (fm != 0u) maxi = -1;
+                        if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                        const uint64_t pkt = EMIT ? (k0 + (uint64_t)((cb + vo0 - p0) / stride)) : 0ull;
+                        confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, pkt, em);
+                    }
+                    /* this lane's position inside its packet, one chunk further */
+                    p0 += step_mod;
+                    p0 = min(p0, p0 - stride);               /* unsigned: subtracts stride iff p0 >= stride */
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
+                cb += KMP_CHUNK;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+    }
+
+    unsigned long long c64 = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+    if (lane == 0u) s_wave_cnt[wave] = c64;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) t += s_wave_cnt[i];
+        partials[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+/* ================================================================================================
+ * Packed arenas of arbitrary payload lengths (real captures, mixed-length traffic): the same flat
+ * streaming as above, with the two things the uniform kernel gets from arithmetic taken from small
+ * side tables built once when the arena is loaded:
+ *   - bitmap: one bit per 16-byte slot of the arena, set where a payload starts (0.8 % of the arena
+ *     size); the 64 bits of a chunk ARE the packet-start ballot, fetched by one scalar load per chunk;
+ *   - plan: per wavefront the first packet index and byte offset of its range.  Ranges are cut at
+ *     packet starts at equal BYTE distance, which is the load balancing for mixed lengths
+ *     (BASELINE configs[4]): every wavefront streams the same number of bytes whatever the lengths.
+ * Lanes learn their packet (index, offset, length) only on the rare path, from the start ballot:
+ * packet index = packets started before this chunk + starts at lanes <= own lane.
+ * ============================================================================================== */
+
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_build_bitmap_kernel(const uint64_t *__restrict__ pkt_off, uint64_t n, unsigned long long *__restrict__ bitmap)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t slot = pkt_off[k] >> 4;
+        atomicOr(bitmap + (slot >> 6), 1ull << (slot & 63ull));
+    }
+}
+
+/* plan[w] = first packet whose offset is >= off[0] + w * bytes_per_wave (w = 0..nwaves); plan[nwaves] = {n, end}. */
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len, uint64_t n, uint64_t nwaves,
+                uint64_t bytes_per_wave, kmp_plan_entry *__restrict__ plan)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > nwaves) return;
+    const uint64_t l16 = ((uint64_t)pkt_len[n - 1] + 15ull) & ~15ull;
+    const uint64_t end = pkt_off[n - 1] + (l16 < 16ull ? 16ull : l16);
+    if (w == nwaves) { plan[w].k = n; plan[w].off = end; return; }
+    const uint64_t target = pkt_off[0] + w * bytes_per_wave;
+    uint64_t lo = 0, hi = n;                       /* lower_bound over the (increasing) offsets */
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pkt_off[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    plan[w].k = lo;
+    plan[w].off = (lo < n) ? pkt_off[lo] : end;
+}
+
+template <int DEPTH, bool MASKED, bool NT, bool EMIT = false>
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
+                       const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,
+                       const kmp_plan_entry *__restrict__ plan, const kmp_pattern_dev *__restrict__ patterns,
+                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
+{
+    __shared__ kmp_pattern_dev s_pat;
+    __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
+
+    const uint32_t pid = pat_ids[blockIdx.y];
+    const kmp_pattern_dev *gp = patterns + pid;
+    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
+        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
+    __syncthreads();
+
+    const PatConst pc = load_pat_const(gp);
+    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint32_t wave = sgpr(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+    if (EMIT) em.pattern = pid;
+    const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
+    const uint64_t off0 = plan[gw].off;
+    const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;    /* planner guarantees < 2^31 */
+
+    uint32_t cnt = 0u;
+    if (range) {
+        const uint8_t *base = arena + off0;
+        const i32x4    rsrc = make_rsrc(base, range);
+        const uint32_t vo0 = lane * KMP_LANE_BYTES;
+        /* packet-start bits of chunk j: bits [b0 + 64 j, +64) of the bitmap = words wi0+j, wi0+j+1 shifted by sh */
+        const uint64_t b0 = off0 >> 4;
+        const unsigned long long *bw = bitmap + (b0 >> 6);
+        const uint32_t sh = (uint32_t)(b0 & 63ull);
+
+        u32x4 buf[DEPTH];
+        unsigned long long hiw[DEPTH];       /* bitmap word wi0 + j + 1 of the chunk in ring slot s */
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+            hiw[s] = bw[s + 1];
+        }
+        unsigned long long low = bw[0];      /* bitmap word wi0 + j of the chunk being consumed */
+        uint64_t kbase = k0 - 1ull;          /* index of the last packet started before the chunk */
+        bool     dead = false;
+        uint32_t cb = 0u, j = 0u;
+
+        while (cb < range) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
+                if (cb < range) {
+                    const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    const u32x4    bn  = buf[(s + 1) % DEPTH];
+                    const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
+                    const unsigned long long hi = hiw[s];
+                    const uint64_t st = sh ? ((low >> sh) | (hi << (64u - sh))) : low;   /* lanes where a packet starts */
+                    low = hi;
+
+                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
+                    const uint32_t fm = filter_min<MASKED>(w, first, mask);
+                    const uint64_t zl = ballot64(zm != 0u);
+                    const uint64_t cl = ballot64(fm == 0u);
+                    const bool dead_in = dead;
+                    if (zl == 0ull) { if (st != 0ull) dead = false; }
+                    else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
+
+                    if (cl != 0ull) {
+                        /* rare path: which packet does a candidate lane sit in? */
+                        int32_t  maxi = -1;
+                        uint32_t p0 = 0u, L = 0u;
+                        uint64_t kl = 0ull;
+                        if (fm == 0u) {
+                            const uint64_t le = (2ull << lane) - 1ull;                  /* lanes <= own (lane 63: all ones) */
+                            kl = kbase + (uint64_t)__builtin_popcountll(st & le);
+                            const uint64_t po = pkt_off[kl];
+                            L  = pkt_len[kl];
+                            p0 = (uint32_t)(off0 + cb + vo0 - po);
+                            maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
+                        }
+                        if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                        confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, kl, em);
+                    }
+                    kbase += (uint64_t)__builtin_popcountll(st);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
+                hiw[s] = bw[j + (uint32_t)DEPTH + 1u];
+                cb += KMP_CHUNK;
+                ++j;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+    }
+
+    unsigned long long c64 = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c64 += __shfl_xor(c64, o);
+    if (lane == 0u) s_wave_cnt[wave] = c64;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) t += s_wave_cnt[i];
+        partials[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+}  // namespace
+
+namespace {
+Emitter emitter_of(const kmp_scan_args &a)
+{
+    Emitter e;
+    e.out = reinterpret_cast<uint4 *>(a.emit_out);
+    e.counter = a.emit_counter;
+    e.cap = a.emit_cap;
+    e.pattern = 0;
+    return e;
+}
+
+template <int DEPTH, bool MASKED>
+hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
+{
+    dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
+    const Emitter em = emitter_of(a);
+#define KMP_FLAT_ARGS a.arena, a.n_pkts, a.uniform_stride, a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials, em
+    if (a.emit_out)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_FLAT_ARGS);
+    else if (a.nontemporal)
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_FLAT_ARGS);
+    else
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, false>), grid, block, 0, st, KMP_FLAT_ARGS);
+#undef KMP_FLAT_ARGS
+    return hipGetLastError();
+}
+template <bool MASKED>
+hipError_t launch_flat_d(const kmp_scan_args &a, hipStream_t st)
+{
+    switch (a.depth) {
+    case 2: return launch_flat_t<2, MASKED>(a, st);
+    case 3: return launch_flat_t<3, MASKED>(a, st);
+    case 5: return launch_flat_t<5, MASKED>(a, st);
+    case 6: return launch_flat_t<6, MASKED>(a, st);
+    case 8: return launch_flat_t<8, MASKED>(a, st);
+    default: return launch_flat_t<4, MASKED>(a, st);
+    }
+}
+}  // namespace
+
+namespace {
+template <int DEPTH, bool MASKED>
+hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
+{
+    dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
+    const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
+    const Emitter em = emitter_of(a);
+#define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, em
+    if (a.emit_out)
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_PACKED_ARGS);
+    else if (a.nontemporal)
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_PACKED_ARGS);
+    else
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, false>), grid, block, 0, st, KMP_PACKED_ARGS);
+#undef KMP_PACKED_ARGS
+    return hipGetLastError();
+}
+}  // namespace
+
+/* Flat streaming kernel for packed arenas of arbitrary payload lengths (bitmap + plan from kmp_launch_prepare_packed). */
+hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st)
+{
+    if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
+    switch (a.depth) {
+    case 3: return a.masked ? launch_packed_t<3, true>(a, st) : launch_packed_t<3, false>(a, st);
+    case 6: return a.masked ? launch_packed_t<6, true>(a, st) : launch_packed_t<6, false>(a, st);
+    default: return a.masked ? launch_packed_t<4, true>(a, st) : launch_packed_t<4, false>(a, st);
+    }
+}
+
+hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned long long *bitmap, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS;
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(kmp_build_bitmap_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, pkt_off, n, bitmap);
+    return hipGetLastError();
+}
+
+hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
+                           void *plan, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (nwaves + 1 + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS;
+    hipLaunchKernelGGL(kmp_plan_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, pkt_off, pkt_len, n, nwaves,
+                       bytes_per_wave, reinterpret_cast<kmp_plan_entry *>(plan));
+    return hipGetLastError();
+}
+
+/* Flat streaming kernel for uniform-stride arenas (a.arena already points at payload 0). */
+hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st)
+{
+    if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
+    return a.masked ? launch_flat_d<true>(a, st) : launch_flat_d<false>(a, st);
+}
+

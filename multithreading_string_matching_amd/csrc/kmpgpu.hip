@@ -1,6 +1,6 @@
 /*
  * kmpgpu.hip -- C-ABI layer over the gfx950 kernels (include/kmpgpu.h).  Host code only; the
- * kernels live in kmp_kernels.hip.  Replaces the state the reference keeps in main()'s locals
+ * kernels live in kmp_scan_*.hip / kmp_prep.hip.  Replaces the state the reference keeps in main()'s locals
  * (array_of_strings / prefix_array / array_of_payloads / string_count, serial.c:54,99,101,148)
  * and the hot loop serial.c:153-155.
  */
