@@ -78,6 +78,10 @@ typedef struct kmpgpu_match {
                                         overwriting it (batches of a streamed capture,
                                         openmp_task.c:172-175); kmpgpu_counts_reset() zeroes it */
 
+#define KMPGPU_OPT_REPACK        7   /* 1 (default) = an arena whose slots are not back to back is
+                                        copied once, on the device, into a packed arena owned by
+                                        the context (streaming kernels); 0 = scan it in place
+                                        with the general kernel                                 */
 #define KMPGPU_OPT_NONTEMPORAL 100   /* 1 (default) = arena loads carry the non-temporal hint (every
                                         byte is read once per pass; measured +10 % on MI355X), 0 =
                                         default cache policy                                   */
@@ -121,7 +125,7 @@ int  kmpgpu_load_frames(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t fil
                         const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads);
 
 /* Same, for an arena already resident in device memory (borrowed; same contract, checked by a
- * device-side pass).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*. */
+ * device-side pass; an arena that is not packed is copied unless KMPGPU_OPT_REPACK is 0).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*. */
 int  kmpgpu_attach_arena(kmpgpu_ctx *ctx, const void *d_arena, uint64_t arena_bytes,
                          const void *d_pkt_off, const void *d_pkt_len, uint64_t n_pkts);
 

@@ -141,6 +141,15 @@ kmp_scatter_index_kernel(const uint64_t *__restrict__ frame_off, const uint32_t 
     }
 }
 
+/* New (packed) slot offsets of an existing index: new_off[k] = scanned slot bytes before payload k. */
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_repack_index_kernel(const uint64_t *__restrict__ loc_off, const uint64_t *__restrict__ blk_bytes, uint64_t n,
+                        uint64_t *__restrict__ new_off)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        new_off[k] = blk_bytes[k / KMP_SCAN_TILE] + loc_off[k];
+}
+
 /* serial.c:125-127 (malloc + memcpy per payload): one wavefront copies one payload into its slot. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_gather_kernel(const uint8_t *__restrict__ file, const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ pkt_off,
@@ -304,6 +313,34 @@ hipError_t kmp_launch_extract_phase2(const uint8_t *file, const uint64_t *frame_
                        blk_bytes, blk_cnt, n, pkt_off, pkt_len, src_off);
     uint32_t gblocks = (uint32_t)std::min<uint64_t>((n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES, 8192);
     hipLaunchKernelGGL(kmp_gather_kernel, dim3(gblocks), dim3(KMP_BLOCK_THREADS), 0, st, file, src_off, pkt_off, pkt_len, n_pkts, arena);
+    return hipGetLastError();
+}
+
+/* Repack an arena whose slots are not back to back (gaps, shuffled order) into a packed one so that the
+ * streaming kernels apply.  Phase 1: scan of the slot sizes (totals[0] = packed bytes).  Phase 2: new
+ * offsets + copy.  ws: kmp_extract_ws_bytes(n) bytes. */
+hipError_t kmp_launch_repack_phase1(const uint32_t *pkt_len, uint64_t n, uint8_t *ws, unsigned long long *totals, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t nblk = (n + KMP_SCAN_TILE - 1) / KMP_SCAN_TILE;
+    uint64_t *loc_off = reinterpret_cast<uint64_t *>(ws);
+    uint64_t *blk_bytes = loc_off + n;
+    uint32_t *loc_idx = reinterpret_cast<uint32_t *>(blk_bytes + nblk) + 2 * n, *blk_cnt = loc_idx + n;
+    hipLaunchKernelGGL(kmp_scan_local_kernel, dim3((uint32_t)nblk), dim3(KMP_BLOCK_THREADS), 0, st, pkt_len, n, loc_off, loc_idx, blk_bytes, blk_cnt);
+    hipLaunchKernelGGL(kmp_scan_totals_kernel, dim3(1), dim3(KMP_BLOCK_THREADS), 0, st, blk_bytes, blk_cnt, (uint32_t)nblk, totals);
+    return hipGetLastError();
+}
+
+hipError_t kmp_launch_repack_phase2(const uint8_t *old_arena, const uint64_t *old_off, const uint32_t *pkt_len, uint64_t n, uint8_t *ws,
+                                    uint8_t *new_arena, uint64_t *new_off, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t *loc_off = reinterpret_cast<const uint64_t *>(ws);
+    const uint64_t *blk_bytes = loc_off + n;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS, 4096);
+    hipLaunchKernelGGL(kmp_repack_index_kernel, dim3(blocks), dim3(KMP_BLOCK_THREADS), 0, st, loc_off, blk_bytes, n, new_off);
+    uint32_t gblocks = (uint32_t)std::min<uint64_t>((n + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES, 8192);
+    hipLaunchKernelGGL(kmp_gather_kernel, dim3(gblocks), dim3(KMP_BLOCK_THREADS), 0, st, old_arena, old_off, new_off, pkt_len, n, new_arena);
     return hipGetLastError();
 }
 

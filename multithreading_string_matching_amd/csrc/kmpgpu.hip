@@ -97,7 +97,7 @@ struct kmpgpu_ctx {
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, fused = 2 /* auto */, accumulate = 0;
+    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, fused = 2 /* auto */, accumulate = 0, repack = 1;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -169,9 +169,51 @@ void release_arena(kmpgpu_ctx *c, bool keep_buffers = false)
     c->d_bitmap = nullptr;
 }
 
+/* An arena whose slots are not back to back (gaps, shuffled order) is copied once into a packed one owned
+ * by the context, so that the streaming kernels apply to it too (KMPGPU_OPT_REPACK, default on). */
+int repack_arena(kmpgpu_ctx *c)
+{
+    if (c->packed || !c->repack || c->n_pkts == 0) return KMPGPU_OK;
+    uint8_t *ws = nullptr, *na = nullptr;
+    uint64_t *noff = nullptr;
+    uint32_t *nlen = nullptr;
+    unsigned long long *d_tot = nullptr, tot[2] = {0, 0};
+    auto drop = [&]() { if (ws) (void)hipFree(ws); if (d_tot) (void)hipFree(d_tot); };
+#define KMP_TRY3(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { drop(); if (na) (void)hipFree(na); if (noff) (void)hipFree(noff); if (nlen) (void)hipFree(nlen); \
+        return fail(KMPGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    KMP_TRY3(hipMalloc(&ws, kmp_extract_ws_bytes(c->n_pkts)));
+    KMP_TRY3(hipMalloc(&d_tot, 2 * sizeof(unsigned long long)));
+    KMP_TRY3(kmp_launch_repack_phase1(c->d_len, c->n_pkts, ws, d_tot, c->stream));
+    KMP_TRY3(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+    KMP_TRY3(hipStreamSynchronize(c->stream));
+    const uint64_t nbytes = tot[0] + 64;
+    KMP_TRY3(hipMalloc(&na, nbytes));
+    KMP_TRY3(hipMalloc(&noff, c->n_pkts * sizeof(uint64_t)));
+    KMP_TRY3(hipMalloc(&nlen, c->n_pkts * sizeof(uint32_t)));
+    KMP_TRY3(hipMemsetAsync(na + tot[0], 0, 64, c->stream));
+    KMP_TRY3(hipMemcpyAsync(nlen, c->d_len, c->n_pkts * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    KMP_TRY3(kmp_launch_repack_phase2(c->d_arena, c->d_off, c->d_len, c->n_pkts, ws, na, noff, c->stream));
+    KMP_TRY3(hipStreamSynchronize(c->stream));
+#undef KMP_TRY3
+    drop();
+    /* the context now owns the packed copy; a borrowed or uploaded original is released */
+    if (c->owned_arena) (void)hipFree(c->owned_arena);
+    if (c->owned_off) (void)hipFree(c->owned_off);
+    if (c->owned_len) (void)hipFree(c->owned_len);
+    c->owned_arena = na; c->owned_off = noff; c->owned_len = nlen;
+    c->cap_arena = nbytes; c->cap_pkts = c->n_pkts;
+    c->d_arena = na; c->d_off = noff; c->d_len = nlen;
+    c->arena_bytes = nbytes;
+    c->packed = true; c->uniform = false;
+    c->uni_off0 = 0; c->span_end = tot[0];
+    return KMPGPU_OK;
+}
+
 /* Side tables of the packed streaming kernel: start bitmap now, wavefront plan on first use. */
 int prepare_packed(kmpgpu_ctx *c)
 {
+    int rc = repack_arena(c);
+    if (rc) return rc;
     if (!c->packed || c->n_pkts == 0) return KMPGPU_OK;
     const size_t words = (size_t)(c->arena_bytes / KMP_CHUNK) + 16;      /* ring prefetch reads up to 8 words past the end */
     HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
@@ -386,6 +428,8 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
     case KMPGPU_OPT_FUSED:
         if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "fused must be 0, 1 or 2");
         c->fused = (int)value; return KMPGPU_OK;
+    case KMPGPU_OPT_REPACK:
+        c->repack = value ? 1 : 0; return KMPGPU_OK;
     case KMPGPU_OPT_ACCUMULATE:
         c->accumulate = value ? 1 : 0; return KMPGPU_OK;
     case KMPGPU_OPT_KERNEL:

@@ -379,9 +379,10 @@ def test_scan_offsets_fixture(gm, tokens, fixture_counts):
         assert text[s0:s0 + len(p)] == p and s0 + len(p) <= E
 
 
-def test_non_packed_arena_takes_the_general_kernel(gm, oracle):
-    """Slots with gaps and in shuffled order: legal for the C-ABI (16-byte aligned, in bounds), not
-    packed, so neither streaming kernel applies."""
+def test_non_packed_arena(gm, oracle):
+    """Slots with gaps and in shuffled order: legal for the C-ABI (16-byte aligned, in bounds) but not
+    packed.  By default the library repacks such an arena once on the device (streaming kernels);
+    with KMPGPU_OPT_REPACK = 0 it is scanned in place by the general kernel."""
     rng = random.Random(17)
     payloads = [bytes(rng.choice(b"abc") for _ in range(rng.randrange(0, 700))) for _ in range(500)]
     order = list(range(len(payloads)))
@@ -398,11 +399,23 @@ def test_non_packed_arena_takes_the_general_kernel(gm, oracle):
     ln = np.array([len(p) for p in payloads], dtype=np.uint32)
     pats = [b"ab", b"abcab", b"b", b"cabcabcabcab"]
     want, _ = oracle.count(arena, off, ln, pats)
+    gm.set_option(OPT_MODE, MODE_FILTER)
     gm.set_patterns(pats)
-    gm.load_arena(arena, off, ln)
-    for kernel in (KERNEL_AUTO, KERNEL_PACKED, KERNEL_GENERAL):
-        gm.set_option(OPT_KERNEL, kernel)
-        assert gm.scan()[0].tolist() == want.tolist()
+    for repack in (1, 0):                      # default: copied once into a packed arena; 0: scanned in place
+        gm.set_option(7, repack)               # KMPGPU_OPT_REPACK
+        gm.load_arena(arena, off, ln)
+        for kernel in (KERNEL_AUTO, KERNEL_PACKED, KERNEL_GENERAL):
+            gm.set_option(OPT_KERNEL, kernel)
+            assert gm.scan()[0].tolist() == want.tolist()
+        a2, off2, ln2 = gm.arena_download()
+        assert ln2.tolist() == ln.tolist()
+        if repack:
+            assert np.all(off2[1:] == off2[:-1] + np.maximum(16, (ln2[:-1].astype(np.uint64) + 15) // 16 * 16)) and off2[0] == 0
+            for k in (0, 7, len(payloads) - 1):
+                assert a2[int(off2[k]):int(off2[k]) + int(ln2[k])].tobytes() == payloads[k]
+        else:
+            assert off2.tolist() == off.tolist()
+    gm.set_option(7, 1)
     gm.set_option(OPT_KERNEL, KERNEL_AUTO)
 
 
