@@ -62,7 +62,7 @@ typedef struct kmpgpu_match {
 /* Option keys for kmpgpu_set_option. */
 #define KMPGPU_OPT_MODE          1   /* 0 auto (filter + KMP verify), 1 KMP automaton only */
 #define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this; 0 = auto (default)    */
-#define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8 (default 4) */
+#define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8; 0 = auto */
 #define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: every pattern of 2..20
                                         bytes is counted in ONE read of a packed arena (the
                                         others keep one read per pattern); 0 = off; 2 = auto

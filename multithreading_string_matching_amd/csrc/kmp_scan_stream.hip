@@ -362,10 +362,10 @@ hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
 hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st)
 {
     if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
-    switch (a.depth) {
-    case 3: return a.masked ? launch_packed_t<3, true>(a, st) : launch_packed_t<3, false>(a, st);
-    case 6: return a.masked ? launch_packed_t<6, true>(a, st) : launch_packed_t<6, false>(a, st);
-    default: return a.masked ? launch_packed_t<4, true>(a, st) : launch_packed_t<4, false>(a, st);
+    switch (a.depth) {          /* 0 = auto: 3 chunks in flight measured best here (profiles/r01_packed_tuning.txt) */
+    case 4: case 5: return a.masked ? launch_packed_t<4, true>(a, st) : launch_packed_t<4, false>(a, st);
+    case 6: case 8: return a.masked ? launch_packed_t<6, true>(a, st) : launch_packed_t<6, false>(a, st);
+    default: return a.masked ? launch_packed_t<3, true>(a, st) : launch_packed_t<3, false>(a, st);
     }
 }
 

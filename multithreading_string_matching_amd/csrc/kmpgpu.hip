@@ -97,7 +97,7 @@ struct kmpgpu_ctx {
     size_t              h_counts_cap = 0;
 
     /* options */
-    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 4, nontemporal = 1, kernel_sel = 0, fused = 2 /* auto */, accumulate = 0, repack = 1;
+    int mode = 0, blocks_per_cu = 0 /* auto */, depth = 0 /* auto */, nontemporal = 1, kernel_sel = 0, fused = 2 /* auto */, accumulate = 0, repack = 1;
 
     /* timing */
     hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -126,10 +126,11 @@ bool use_packed(const kmpgpu_ctx *c)
 
 uint32_t grid_blocks(const kmpgpu_ctx *c)
 {
-    /* persistent grid: measured best on MI355X is 4 blocks/CU for the streaming kernels (HBM-bound
-     * from 2 blocks/CU on) and 8 for the general kernel */
+    /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat and fused kernels (HBM-bound
+     * from 2 blocks/CU on), 6 for the packed kernel (profiles/r01_packed_tuning.txt), 8 for the general one */
     const bool streaming = use_flat(c) || use_packed(c);
-    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : (streaming ? 4 : 8);
+    const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
+                  : !streaming ? 8 : (use_packed(c) && !use_flat(c) && !use_fused(c)) ? 6 : 4;
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
     if (streaming && c->blocks_per_cu <= 0) {
         /* small captures: give every wavefront at least 8 KiB to stream instead of launching
@@ -243,7 +244,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
 
     kmp_scan_args a{};
     a.arena = c->d_arena; a.pkt_off = c->d_off; a.pkt_len = c->d_len; a.n_pkts = c->n_pkts;
-    a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; a.mode = c->mode;
+    a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; /* 0: the launcher's own default */ a.mode = c->mode;
     a.nontemporal = c->nontemporal != 0;
     if (emit) { a.emit_out = emit->out; a.emit_counter = emit->counter; a.emit_cap = emit->cap; }
     /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
@@ -423,7 +424,7 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
         if (value < 0 || value > 64) return fail(KMPGPU_EINVAL, "blocks per CU must be 0 (auto) or 1..64");
         c->blocks_per_cu = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_DEPTH:
-        if (value < 2 || value > 8 || value == 7) return fail(KMPGPU_EINVAL, "depth must be 2..6 or 8");
+        if (value != 0 && (value < 2 || value > 8 || value == 7)) return fail(KMPGPU_EINVAL, "depth must be 0 (auto), 2..6 or 8");
         c->depth = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_FUSED:
         if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "fused must be 0, 1 or 2");

@@ -36,7 +36,7 @@ def gm():
 KERNEL_FUSED = 100          # test-only alias: auto kernel selection + the fused multi-pattern pass
 
 
-def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=4, kernel=KERNEL_AUTO):
+def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=0, kernel=KERNEL_AUTO):
     gm.set_option(OPT_MODE, mode)
     gm.set_option(OPT_DEPTH, depth)
     gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
@@ -56,7 +56,7 @@ VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED), (MODE_FILT
             (MODE_AUTOMATON, KERNEL_GENERAL))
 
 
-def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=4):
+def check_payloads(gm, oracle, payloads, patterns, variants=VARIANTS, depth=0):
     arena = K.HostArena.from_payloads(payloads)
     want, _ = oracle.count(arena.bytes, arena.off, arena.len, patterns)
     for mode, kernel in variants:
@@ -189,8 +189,8 @@ def test_uniform_length_arenas_with_nuls(gm, oracle, L):
             b[0] = 0
         payloads.append(bytes(b))
     check_payloads(gm, oracle, payloads, pats)
-    for depth in (2, 3, 5, 6, 8):
-        check_payloads(gm, oracle, payloads[:97], pats[:3], variants=((MODE_FILTER, KERNEL_AUTO),), depth=depth)
+    for depth in (2, 3, 4, 5, 6, 8):
+        check_payloads(gm, oracle, payloads[:97], pats[:3], variants=((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED)), depth=depth)
 
 
 def test_uniform_length_few_packets(gm, oracle):
