@@ -80,6 +80,40 @@ __global__ void __launch_bounds__(256) read_block(const u32x4 *__restrict__ src,
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// packet-interleaved inside a block: the block owns a contiguous run of 1504-byte slots, wavefront w streams
+// the slots with index % 4 == w as ONE logical byte stream cut into 1 KiB chunks (lane slot t -> packet t/94)
+template <int INFL, bool NT>
+__global__ void __launch_bounds__(256) read_pktil(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t pkts = n16 / 94u, per = ((pkts + gridDim.x - 1) / gridDim.x + 3u) & ~3ull;
+    const uint64_t p0 = (uint64_t)blockIdx.x * per, p1 = std::min(pkts, p0 + per);
+    const uint32_t mine = p1 > p0 ? (uint32_t)((p1 - p0 + 3u - wave) / 4u) : 0u;       // packets of this wavefront
+    const uint32_t slots = mine * 94u, chunks = (slots + 63u) / 64u;
+    const u32x4 *base = src + p0 * 94u;
+    u32x4 acc = {0, 0, 0, 0};
+    uint32_t c = 0;
+    for (; c + INFL <= chunks; c += INFL) {
+        u32x4 v[INFL];
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) {
+            uint32_t t = (c + i) * 64u + lane;
+            t = t < slots ? t : slots - 1u;
+            const uint32_t q = t / 94u, r = t - q * 94u;
+            v[i] = ld16<NT>(base + (uint64_t)(q * 4u + wave) * 94u + r);
+        }
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) acc ^= v[i];
+    }
+    for (; c < chunks; ++c) {
+        uint32_t t = c * 64u + lane;
+        t = t < slots ? t : slots - 1u;
+        const uint32_t q = t / 94u, r = t - q * 94u;
+        acc ^= ld16<NT>(base + (uint64_t)(q * 4u + wave) * 94u + r);
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 template <typename F> double sustained_us(F launch)
 {
     const int warm = 60, n = 100;
@@ -111,7 +145,7 @@ int main()
 #define RUN(name, kern, bpc) do { const int b_ = cus * (bpc); \
         double us = sustained_us([&] { hipLaunchKernelGGL(kern, dim3(b_), dim3(256), 0, 0, s, n16, out); }); \
         printf("%-44s blocks/CU=%d  %7.1f us  %6.0f GB/s\n", name, bpc, us, bytes / us / 1e3); fflush(stdout); } while (0)
-    for (int bpc : {2, 4, 8}) {
+    for (int bpc : {2, 3, 4, 8}) {
         RUN("range/wave  4 in flight nt", (read_range<4, true>), bpc);
         RUN("range/wave  8 in flight nt", (read_range<8, true>), bpc);
         RUN("range/wave  4 in flight   ", (read_range<4, false>), bpc);
@@ -120,6 +154,8 @@ int main()
         RUN("grid-stride 4 in flight   ", (read_stride<4, false>), bpc);
         RUN("range/block 4 in flight nt", (read_block<4, true>), bpc);
         RUN("range/block 8 in flight nt", (read_block<8, true>), bpc);
+        RUN("packet-interleave/block 4 in flight nt", (read_pktil<4, true>), bpc);
+        RUN("packet-interleave/block 3 in flight nt", (read_pktil<3, true>), bpc);
     }
     return 0;
 }
