@@ -66,7 +66,7 @@ typedef struct kmpgpu_match {
 #define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: every pattern of 2..20
                                         bytes is counted in ONE read of a packed arena (the
                                         others keep one read per pattern); 0 = off; 2 = auto
-                                        (default): fused from 5 such unique patterns on       */
+                                        (default): fused from 3 such unique patterns on       */
 #define KMPGPU_OPT_KERNEL        5   /* 0 auto: flat streaming kernel when every payload has the
                                         same length and the slots are back to back, packed
                                         streaming kernel when the slots are back to back with

@@ -28,24 +28,26 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 
 /* Tables of the fused multi-pattern kernel (kmp_scan_multi_kernel), one blob of uint32 words built on
  * the host (kmpgpu_set_patterns) and copied into LDS by every block:
- *   [0, 2048)        bit KMP_MULTI_BIT(b0 | b1 << 8) set iff some pattern starts with the bytes b0 b1 (the
- *                    odd multiplier is a bijection of the 16-bit index; it spreads text, whose bytes share
- *                    their high bits, over the LDS banks -- plain indexing put ASCII letters on 4 banks)
- *   [2048, 2560)     1024 x uint16: first entry of the bucket hash(b0 | b1 << 8), 0xFFFF = empty
- *   [2560, 3072)     entries, uint32 each: unique-pattern id (bits 0-7) | third pattern byte << 8 (0 when the
+ *   [0, 512)         1024 x uint16: first entry of the bucket hash(b0 | b1 << 8), 0xFFFF = empty
+ *   [512, 1024)      entries, uint32 each: unique-pattern id (bits 0-7) | third pattern byte << 8 (0 when the
  *                    pattern has 2 bytes: nothing to pre-check) | 0x80000000 on the last entry of a bucket
- *   [3072, ...)      one 12-word record per unique pattern: 5 pattern dwords, 5 byte masks, m, 0 */
-#define KMP_MULTI_B2_WORDS    2048u
+ *   [1024, 3072)     64 Kbit filter over the first THREE text bytes: bit h = KMP_MULTI_BIT(b0 | b1 << 8 |
+ *                    b2 << 16) (byte h >> 3, bit h & 7) is set for every pattern of 3+ bytes, and for all 256
+ *                    values of b2 for a 2-byte pattern (so one lookup serves both).  The multiplicative
+ *                    hash also spreads text, whose bytes share their high bits, over the LDS banks.
+ *   [3072, ...)      one 12-word record per unique pattern: 5 pattern dwords, 5 byte masks, m, 0
+ * The first 3072 words live in static LDS (their offsets fold into the ds_read offset field). */
 #define KMP_MULTI_BUCKETS     1024u
-#define KMP_MULTI_BUCKET_W0   2048u
-#define KMP_MULTI_ENTRY_W0    2560u
+#define KMP_MULTI_BUCKET_W0   0u
+#define KMP_MULTI_ENTRY_W0    512u
 #define KMP_MULTI_MAX_ENTRIES 512u
+#define KMP_MULTI_FILTER_W0   1024u
 #define KMP_MULTI_REC_W0      3072u
 #define KMP_MULTI_REC_WORDS   12u
 #define KMP_MULTI_MAX_UNIQUE  256u
 #define KMP_MULTI_MIN_LEN     2u
 #define KMP_MULTI_MAX_LEN     20u
-#define KMP_MULTI_BIT(w16)    ((((uint32_t)(w16) & 0xFFFFu) * 0x9E3Bu) & 0xFFFFu)
+#define KMP_MULTI_BIT(w24)    ((((uint32_t)(w24) & 0xFFFFFFu) * 0x9E3779u) >> 16)   /* v_mul_u32_u24, 16-bit hash */
 #define KMP_MULTI_HASH(w16)   ((((uint32_t)(w16) * 0x9E3Bu) >> 6) & (KMP_MULTI_BUCKETS - 1u))
 
 #endif

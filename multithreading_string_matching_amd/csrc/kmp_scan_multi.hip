@@ -20,8 +20,8 @@ namespace {
  * balanced plan).  Per chunk:
  *   - rem = payload bytes left from the lane's first byte (uniform loop over the packet starts of the
  *     chunk; lengths come by scalar loads, offsets are implied by the bitmap because the arena is packed);
- *   - level 1: the 2-byte window at each of the 16 start offsets indexes a 64 Kbit LDS bitmap "some
- *     pattern starts with these two bytes" -> 16-bit hit mask per lane;
+ *   - level 1: the 3-byte window at each of the 16 start offsets is hashed into a 64 Kbit LDS filter "some
+ *     pattern may start with these bytes" (2-byte patterns set all 256 third bytes) -> 16-bit hit mask per lane;
  *   - level 2, per start offset that has a hit in some lane: hash the 2 bytes to a bucket, walk the
  *     bucket's short list of patterns, compare up to 20 bytes dword-wise with byte masks (text from
  *     registers, pattern records from LDS), check window-in-payload and the strlen() rule, and bump
@@ -34,14 +34,21 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,
                       unsigned long long *__restrict__ partials)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];    /* tables, counters, then one chunk window per wavefront */
-    uint32_t *s_cnt = s_tab + table_words;
-    uint32_t *s_win = s_tab + ((table_words + n_unique + 3u) & ~3u);
-    for (uint32_t i = threadIdx.x; i < table_words; i += KMP_BLOCK_THREADS) s_tab[i] = tables[i];
+    /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
+     * into the ds_read offset field; records, counters and one chunk window per wavefront follow dynamically */
+    __shared__ __attribute__((aligned(16))) uint32_t s_fix[KMP_MULTI_REC_W0];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const uint32_t rec_words = table_words - KMP_MULTI_REC_W0;
+    uint32_t *s_rec = s_dyn;
+    uint32_t *s_cnt = s_dyn + rec_words;
+    uint32_t *s_win = s_dyn + ((rec_words + n_unique + 3u) & ~3u);
+    for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0; i += KMP_BLOCK_THREADS) s_fix[i] = tables[i];
+    for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
     for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
     __syncthreads();
-    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_tab + KMP_MULTI_BUCKET_W0);
-    const uint32_t *s_entry  = s_tab + KMP_MULTI_ENTRY_W0;
+    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_fix + KMP_MULTI_BUCKET_W0);
+    const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
+    const uint8_t  *s_filter = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
 
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
@@ -103,16 +110,16 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     }
                     remc = remn;
 
-                    /* level 1: which start offsets begin with the first two bytes of some pattern? */
+                    /* level 1: which start offsets may begin some pattern (filter over the first three bytes)? */
                     uint32_t hm = 0u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
-                            const uint32_t bi = (d0 & 0xFFFFu) * 0x9E3Bu;                              /* KMP_MULTI_BIT: bank spreading */
-                            const uint32_t word = s_tab[(bi >> 5) & 0x7FFu];
-                            hm |= ((word >> (bi & 31u)) & 1u) << (4 * q + a);
+                            const uint32_t pr = __umul24(d0, 0x9E3779u);                               /* KMP_MULTI_BIT = pr >> 16: hash of 3 text bytes */
+                            const uint32_t fb = s_filter[pr >> 19];
+                            hm |= __builtin_amdgcn_ubfe(fb, (pr >> 16) & 7u, 1u) << (4 * q + a);
                         }
                     }
                     if (ballot64(hm != 0u) != 0ull) {
@@ -138,14 +145,14 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                     const uint32_t r0 = src[0], r1 = src[1];
                                     const uint32_t T0 = __builtin_amdgcn_alignbyte(r1, r0, sa);
                                     const uint32_t b2 = (T0 >> 16) & 0xFFu;             /* third text byte: cheap pre-check per entry */
-                                    uint32_t e = s_bucket[KMP_MULTI_HASH(T0 & 0xFFFFu)];
+                                    uint32_t e = s_bucket[(__umul24(T0, 0x9E3Bu) >> 6) & (KMP_MULTI_BUCKETS - 1u)];   /* KMP_MULTI_HASH: bits 6..15 see 2 bytes only */
                                     while (e != 0xFFFFu) {
                                         const uint32_t ent = s_entry[e];
                                         const uint32_t pb2 = (ent >> 8) & 0xFFu;
                                         if (pb2 == 0u || pb2 == b2) {
                                             /* rare: fetch the other 16 text bytes and the pattern record */
                                             const uint32_t uid = ent & 0xFFu;
-                                            const uint32_t *rec = s_tab + KMP_MULTI_REC_W0 + uid * KMP_MULTI_REC_WORDS;
+                                            const uint32_t *rec = s_rec + uid * KMP_MULTI_REC_WORDS;
                                             uint32_t diff = (T0 ^ rec[0]) & rec[5];
                                             uint32_t prev = r1;
 #pragma unroll
@@ -187,7 +194,7 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
-    const size_t lds = ((size_t)((table_words + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
+    const size_t lds = ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
     if (a.nontemporal)
         hipLaunchKernelGGL((kmp_scan_multi_kernel<4, true>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, a.arena, a.pkt_len,
                            a.bitmap, plan, tables, table_words, n_unique, a.partials);

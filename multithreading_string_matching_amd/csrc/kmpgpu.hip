@@ -110,13 +110,13 @@ struct kmpgpu_ctx {
 namespace {
 
 bool use_flat(const kmpgpu_ctx *c) { return c->uniform && c->kernel_sel == 0 && c->mode == 0; }
-/* Fused multi-pattern pass: explicit (1) or automatic (2: from 5 unique eligible patterns on, where it
+/* Fused multi-pattern pass: explicit (1) or automatic (2: from 3 unique eligible patterns on, where it
  * beats one streaming pass per pattern -- profiles/r01_multipattern.txt). */
 bool use_fused(const kmpgpu_ctx *c)
 {
     if (!c->packed || !c->d_bitmap || c->mode != 0 || c->kernel_sel == 1 || !c->d_multi_tables) return false;
     if (c->fused == 1) return c->n_multi_unique >= 2;
-    return c->fused == 2 && c->n_multi_unique >= 5;
+    return c->fused == 2 && c->n_multi_unique >= 3;
 }
 
 bool use_packed(const kmpgpu_ctx *c)
@@ -126,11 +126,12 @@ bool use_packed(const kmpgpu_ctx *c)
 
 uint32_t grid_blocks(const kmpgpu_ctx *c)
 {
-    /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat and fused kernels (HBM-bound
-     * from 2 blocks/CU on), 6 for the packed kernel (profiles/r01_packed_tuning.txt), 8 for the general one */
+    /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat kernel (HBM-bound from 3 on), 6 for
+     * the packed kernel (profiles/r01_packed_tuning.txt), 7 for the fused pass (latency-bound level 2; 7 blocks
+     * of LDS fit a CU; profiles/r01_fused_blocks_per_cu.txt), 8 for the general one */
     const bool streaming = use_flat(c) || use_packed(c);
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
-                  : !streaming ? 8 : (use_packed(c) && !use_flat(c) && !use_fused(c)) ? 6 : 4;
+                  : use_fused(c) ? 7 : !streaming ? 8 : use_flat(c) ? 4 : 6;
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
     if (streaming && c->blocks_per_cu <= 0) {
         /* small captures: give every wavefront at least 8 KiB to stream instead of launching
@@ -526,8 +527,12 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         for (uint32_t u = 0; u < U; u++) {
             const std::string &p = uniq[u];
             const uint32_t w16 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8);
-            const uint32_t bi = KMP_MULTI_BIT(w16);
-            tab[bi >> 5] |= 1u << (bi & 31u);
+            for (uint32_t t = 0; t < 256u; t++) {                     /* a 2-byte pattern matches whatever follows it */
+                const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : t;
+                const uint32_t bi = KMP_MULTI_BIT(w16 | (third << 16));
+                tab[KMP_MULTI_FILTER_W0 + (bi >> 5)] |= 1u << (bi & 31u);
+                if (p.size() >= 3) break;
+            }
             lists[KMP_MULTI_HASH(w16)].push_back(u);
             uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)u * KMP_MULTI_REC_WORDS;
             for (uint32_t b = 0; b < p.size(); b++) {

@@ -19,6 +19,7 @@ from ._lib import KmpGpuError, Match, SynthParams, Timing, gpu_check, u8p, u32p,
 from .host import HostArena
 
 OPT_MODE, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_ACCUMULATE, OPT_NONTEMPORAL = 1, 2, 3, 4, 5, 6, 100
+OPT_REPACK = 7
 KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED = 0, 1, 2
 MODE_FILTER, MODE_AUTOMATON = 0, 1
 

@@ -315,6 +315,25 @@ def test_fused_multi_pattern_edge_cases(gm, oracle):
     check_payloads(gm, oracle, payloads[:200], many, variants=((MODE_FILTER, KERNEL_FUSED),))
 
 
+def test_fused_binary_text(gm, oracle):
+    """Fused pass, level-1 filter over the first three text bytes, on binary payloads (all byte values, so
+    2-byte patterns are followed by any third byte, 0x00 and the end of the payload included)."""
+    rng = random.Random(77)
+    pats = [b"\x01\x02", b"\xff\xfe", b"\x01\x02\x03", b"\x80\x81\x82\x83", b"zz", b"\x7f" * 5, b"\x01\x02\xff\x01\x02", b"\xfe\xff",
+            bytes(range(1, 21)), b"\x02\x01"]
+    payloads = []
+    for k in range(400):
+        L = rng.choice([2, 3, 4, 17, 64, 333, 1024, 1500, 2048])
+        b = bytearray(rng.randrange(256) for _ in range(L))
+        for _ in range(L // 24 + 1):
+            p = rng.choice(pats)
+            if len(p) <= L:
+                s0 = rng.choice([0, L - len(p), rng.randrange(0, L - len(p) + 1)])
+                b[s0:s0 + len(p)] = p
+        payloads.append(bytes(b))
+    check_payloads(gm, oracle, payloads, pats, variants=((MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_PACKED)))
+
+
 # ------------------------------------------------------------------------------------------------
 # match offsets (north_star: "per-pattern match counts/offsets out")
 # ------------------------------------------------------------------------------------------------

@@ -17,11 +17,12 @@ d_arena = torch.zeros(n * 1504 + 64, dtype=torch.uint8, device="cuda")
 d_off = torch.empty(n, dtype=torch.int64, device="cuda"); d_len = torch.empty(n, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize(); m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp); m.sync()
 m.set_option(OPT_FUSED, 1)
-for np_ in (8, 97):
+for np_ in (3, 8, 97):
     m.set_patterns(pats[:np_]); m.attach_arena(d_arena, d_off, d_len)
-    for bpc in (2, 4, 6, 7, 8, 10, 12):
+    for bpc in (3, 4, 5, 6, 7, 8):
         m.set_option(OPT_BLOCKS_PER_CU, bpc)
-        m.scan()
-        ts = [m.scan()[1].kernel_ms for _ in range(5)]
-        print(f"{np_} patterns bpc={bpc}: {np.median(ts):.3f} ms -> {n*L/np.median(ts)/1e6:.1f} GB/s payload")
+        for _ in range(20): m.scan_enqueue()
+        m.sync()
+        ts = [m.scan()[1].kernel_ms for _ in range(7)]
+        print(f"{np_} patterns bpc={bpc}: {np.median(ts):.3f} ms -> {n*L/np.median(ts)/1e6:.1f} GB/s payload", flush=True)
 m.close()
