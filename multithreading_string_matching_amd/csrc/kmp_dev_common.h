@@ -128,6 +128,13 @@ __device__ __forceinline__ PatConst load_pat_const(const kmp_pattern_dev *gp)
         pc.pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
         pc.pm[d] = (pc.m >= lo + 4u) ? 0xFFFFFFFFu : (pc.m <= lo) ? 0u : ((1u << (8u * (pc.m - lo))) - 1u);
     }
+    /* Take the scalar loads' results HERE.  Left alone the compiler postpones the s_waitcnt lgkmcnt(0) to the
+     * first use of each constant, i.e. to several places inside the streaming loop, where such a wait also
+     * covers the bitmap words the loop has just asked for (scalar loads return out of order: only lgkmcnt(0)
+     * exists for them). */
+    asm volatile("" : "+s"(pc.m), "+s"(pc.first), "+s"(pc.mask));
+    asm volatile("" : "+s"(pc.pd[0]), "+s"(pc.pd[1]), "+s"(pc.pd[2]), "+s"(pc.pd[3]));
+    asm volatile("" : "+s"(pc.pm[0]), "+s"(pc.pm[1]), "+s"(pc.pm[2]), "+s"(pc.pm[3]));
     return pc;
 }
 

@@ -54,7 +54,10 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
     const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
-    const uint64_t off0 = plan[gw].off;
+    /* the stream starts on the 128-byte line below the first packet (see kmp_scan_packed_kernel) */
+    const uint64_t off_first = plan[gw].off;
+    const uint32_t pre = (uint32_t)(off_first & 127ull), pl = pre >> 4;
+    const uint64_t off0 = off_first - pre;
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;
 
     if (range) {
@@ -78,15 +81,30 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
         uint32_t cb = 0u, j = 0u;
 
         while (cb < range) {
+            /* packet-start words: use this group's, then ask for the next group's (see kmp_scan_packed_kernel) */
+            uint64_t st_[DEPTH];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                const unsigned long long hi = hiw[s];
+                st_[s] = sh ? ((low >> sh) | (hi << (64u - sh))) : low;
+                low = hi;
+                asm volatile("" : "+s"(st_[s]));      /* computed HERE, not sunk below the loads that follow */
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[j + (uint32_t)DEPTH + 1u + (uint32_t)s];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
                 ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
                 if (cb < range) {
-                    const uint4 v  = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    uint4 v = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
                     const u32x4 bn = buf[(s + 1) % DEPTH];
-                    const unsigned long long hi = hiw[s];
-                    uint64_t st = sh ? ((low >> sh) | (hi << (64u - sh))) : low;
-                    low = hi;
+                    uint64_t st = st_[s];
+                    if (s == 0 && cb == 0u && pl != 0u) {                               /* lanes before the first packet: not ours */
+                        if (lane < pl) v = make_uint4(0u, 0u, 0u, 0u);
+                        st &= ~0ull << pl;
+                    }
                     const uint32_t left = range - cb;
                     if (left < KMP_CHUNK) st &= (1ull << (left >> 4)) - 1ull;        /* bits past the range belong to the next wavefront */
 
@@ -172,7 +190,6 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
-                hiw[s] = bw[j + (uint32_t)DEPTH + 1u];
                 cb += KMP_CHUNK;
                 ++j;
             }

@@ -210,7 +210,14 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
     if (EMIT) em.pattern = pid;
     const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
-    const uint64_t off0 = plan[gw].off;
+    /* The range starts at a packet start (16-byte aligned).  Streaming from there would make every 1 KiB chunk
+     * load straddle nine 128-byte lines instead of covering eight, and the line shared by two consecutive
+     * chunks is fetched from HBM twice under the streaming (nt) policy: +4.5 % traffic measured.  So the
+     * stream starts on the line boundary below; the `pl` lanes of the first chunk that precede the first
+     * packet belong to the previous wavefront and are blanked (zero bytes, no start bits). */
+    const uint64_t off_first = plan[gw].off;
+    const uint32_t pre = (uint32_t)(off_first & 127ull), pl = pre >> 4;
+    const uint64_t off0 = off_first - pre;
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;    /* planner guarantees < 2^31 */
 
     uint32_t cnt = 0u;
@@ -224,7 +231,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
         const uint32_t sh = (uint32_t)(b0 & 63ull);
 
         u32x4 buf[DEPTH];
-        unsigned long long hiw[DEPTH];       /* bitmap word wi0 + j + 1 of the chunk in ring slot s */
+        unsigned long long hiw[DEPTH];       /* bitmap word wi0 + j + 1 of the chunk in ring slot s, fetched one group ahead */
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
             flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
@@ -236,16 +243,34 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
         uint32_t cb = 0u, j = 0u;
 
         while (cb < range) {
+            /* Packet-start words, one GROUP of ring slots ahead.  Scalar loads return out of order, so the only
+             * wait that covers them is lgkmcnt(0) -- which also waits for a load issued a moment ago.  Using this
+             * group's words first (they have had a whole group of chunks to arrive) and only then asking for the
+             * next group's keeps that wait off the critical path. */
+            uint64_t st_[DEPTH];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                const unsigned long long hi = hiw[s];
+                st_[s] = sh ? ((low >> sh) | (hi << (64u - sh))) : low;                   /* lanes where a packet starts */
+                low = hi;
+                asm volatile("" : "+s"(st_[s]));      /* computed HERE, not sunk below the loads that follow */
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[j + (uint32_t)DEPTH + 1u + (uint32_t)s];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
                 ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
                 if (cb < range) {
-                    const uint4    v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
+                    uint4          v   = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
                     const u32x4    bn  = buf[(s + 1) % DEPTH];
+                    uint64_t       st  = st_[s];
+                    if (s == 0 && cb == 0u && pl != 0u) {                               /* head of the range, see above */
+                        if (lane < pl) v = make_uint4(0u, 0u, 0u, 0u);
+                        st &= ~0ull << pl;
+                    }
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
-                    const unsigned long long hi = hiw[s];
-                    const uint64_t st = sh ? ((low >> sh) | (hi << (64u - sh))) : low;   /* lanes where a packet starts */
-                    low = hi;
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
                     const uint32_t fm = filter_min<MASKED>(w, first, mask);
@@ -270,12 +295,15 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                         }
                         if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
                         confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, kl, em);
+                        /* leave nothing of the rare path's LDS/scalar reads "possibly in flight": merged into the
+                         * common path that state costs an s_waitcnt lgkmcnt(0) per chunk, which would also wait
+                         * for the bitmap words just asked for */
+                        __builtin_amdgcn_s_waitcnt(0xC07F);      /* lgkmcnt(0) only */
                     }
                     kbase += (uint64_t)__builtin_popcountll(st);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
-                hiw[s] = bw[j + (uint32_t)DEPTH + 1u];
                 cb += KMP_CHUNK;
                 ++j;
             }

@@ -217,7 +217,7 @@ int prepare_packed(kmpgpu_ctx *c)
     int rc = repack_arena(c);
     if (rc) return rc;
     if (!c->packed || c->n_pkts == 0) return KMPGPU_OK;
-    const size_t words = (size_t)(c->arena_bytes / KMP_CHUNK) + 16;      /* ring prefetch reads up to 8 words past the end */
+    const size_t words = (size_t)(c->arena_bytes / KMP_CHUNK) + 32;      /* the group prefetch reads up to 2 * DEPTH + 1 words past the end */
     HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->d_bitmap, 0, words * sizeof(unsigned long long), c->stream));
     HIP_TRY(kmp_launch_build_bitmap(c->d_off, c->n_pkts, c->d_bitmap, c->stream));
