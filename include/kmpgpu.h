@@ -172,6 +172,10 @@ int  kmpgpu_fixed_index(kmpgpu_ctx *ctx, void *d_pkt_off, void *d_pkt_len, uint6
 
 /* What the arena currently attached/loaded holds. */
 int  kmpgpu_arena_info(kmpgpu_ctx *ctx, uint64_t *n_pkts, uint64_t *payload_bytes);
+/* Sum over payloads of min(len, first 0x00 + 1): the bytes a strlen()-bounded scan (serial.c:191) has to
+ * touch; equals payload_bytes on NUL-free input.  Reported beside the payload bytes for inputs that carry
+ * NUL bytes; one extra pass over the arena, not part of kmpgpu_scan. */
+int  kmpgpu_effective_bytes(kmpgpu_ctx *ctx, uint64_t *bytes_out);
 /* Copy the context's device arena + index back to host buffers (tests: the on-device extraction must
  * build exactly the arena the host builds).  Buffers sized from kmpgpu_arena_info / arena_bytes. */
 int  kmpgpu_arena_download(kmpgpu_ctx *ctx, uint8_t *arena_out, uint64_t arena_cap, uint64_t *arena_bytes,

@@ -138,6 +138,7 @@ GPU_API = {
     "kmpgpu_synth_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(SynthParams)]),
     "kmpgpu_fixed_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
     "kmpgpu_arena_info": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "kmpgpu_effective_bytes": (C.c_int, [C.c_void_p, u64p]),
 }
 
 

@@ -134,6 +134,11 @@ int main(int argc, char *argv[])
     for (uint32_t i = 0; i < pats.n; i++) pp[i] = pats.blob + pats.off[i];
 
     double kernel_ms = 0, h2d_ms = 0;
+    /* KMPGPU_STATS=1: also report the bytes up to the first NUL of every payload (what strlen bounds, serial.c:191);
+     * one extra pass over the arena, so it is opt-in and the "Elapsed time" line of a plain run stays comparable */
+    const char *stats_env = getenv("KMPGPU_STATS");
+    const int want_stats = stats_env && stats_env[0] && stats_env[0] != '0';
+    uint64_t eff_bytes = 0;
     if (pats.n && device_extract && frames.n) {
         /* frames split like mpi_dumping.c:149-157; every shard extracts and counts its own frames */
         if ((uint64_t)shards > frames.n) shards = (int)frames.n;
@@ -154,6 +159,7 @@ int main(int argc, char *argv[])
             for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];
             if (t.kernel_ms > kernel_ms) kernel_ms = t.kernel_ms;
             h2d_ms += t.h2d_ms;
+            if (want_stats) { uint64_t e = 0; if (kmpgpu_effective_bytes(ctx, &e)) die_gpu("kmpgpu_effective_bytes"); eff_bytes += e; }
             kmpgpu_destroy(ctx);
             lo += cnt;
         }
@@ -208,6 +214,11 @@ int main(int argc, char *argv[])
             shard_lo += arena.n_pkts / (uint64_t)shards + (r == 0 ? arena.n_pkts % (uint64_t)shards : 0);
         }
         if (off_fp) fclose(off_fp);
+        for (int r = 0; r < shards && want_stats; r++) {
+            uint64_t e = 0;
+            if (kmpgpu_effective_bytes(ctx[r], &e)) die_gpu("kmpgpu_effective_bytes");
+            eff_bytes += e;
+        }
         for (int r = 0; r < shards; r++) kmpgpu_destroy(ctx[r]);
         free(ctx); free(reb);
     }
@@ -224,6 +235,9 @@ int main(int argc, char *argv[])
                 pats.n, shards, ndev);
         fprintf(stderr, "[kmpgpu] kernel %.3f ms (%.2f GB/s payload x patterns, %.3g matches/s), h2d %.3f ms\n", kernel_ms,
                 bytes / (kernel_ms * 1e6), (double)total / (kernel_ms * 1e-3), h2d_ms);
+        if (want_stats)
+            fprintf(stderr, "[kmpgpu] %llu of the %llu payload bytes lie at or before the first NUL of their payload\n",
+                    (unsigned long long)eff_bytes, (unsigned long long)arena.payload_bytes);
     }
     free(counts); free(part); free(pp);
     kmp_arena_free(&arena);

@@ -53,6 +53,8 @@ hipError_t kmp_launch_extract_phase2(const uint8_t *file, const uint64_t *frame_
 hipError_t kmp_launch_repack_phase1(const uint32_t *pkt_len, uint64_t n, uint8_t *ws, unsigned long long *totals, hipStream_t st);
 hipError_t kmp_launch_repack_phase2(const uint8_t *old_arena, const uint64_t *old_off, const uint32_t *pkt_len, uint64_t n, uint8_t *ws,
                                     uint8_t *new_arena, uint64_t *new_off, hipStream_t st);
+hipError_t kmp_launch_effective_bytes(const uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n,
+                                      unsigned long long *out, hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,
                                uint32_t *err, unsigned long long *payload_bytes, hipStream_t st);
 hipError_t kmp_launch_synth_fill(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t first_pkt_id,

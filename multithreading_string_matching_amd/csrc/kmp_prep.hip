@@ -353,6 +353,58 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
     return hipGetLastError();
 }
 
+/* Sum over packets of min(len, first 0x00 + 1): the bytes a strlen()-bounded scan (serial.c:191) has to
+ * touch.  One wavefront per packet, 1 KiB per step; SURVEY 8(d) asks for this figure beside the payload
+ * bytes when the input carries NUL bytes.  Not on the hot path (one pass, on request). */
+namespace {
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_effective_bytes_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
+                           const uint32_t *__restrict__ pkt_len, uint64_t n, unsigned long long *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint64_t nw = (uint64_t)gridDim.x * KMP_BLOCK_WAVES;
+    unsigned long long acc = 0ull;
+    for (uint64_t k = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + (threadIdx.x >> 6); k < n; k += nw) {
+        const uint32_t L = pkt_len[k];
+        const uint8_t *p = arena + pkt_off[k];
+        uint32_t eff = L;
+        for (uint32_t base = 0u; base < L; base += KMP_CHUNK) {
+            const uint32_t o = base + lane * KMP_LANE_BYTES;
+            uint32_t first = 16u;                                  /* index of the lane's first 0x00 among its payload bytes */
+            if (o < L) {                                           /* slots are padded to 16 bytes: the whole group is readable */
+                const uint4 v = *reinterpret_cast<const uint4 *>(p + o);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int d = 3; d >= 0; --d) {
+                    const uint32_t z = zero_byte_mask(w[d]);
+                    if (z) first = 4u * (uint32_t)d + ((uint32_t)__builtin_ctz(z) >> 3);
+                }
+                if (o + first >= L) first = 16u;                   /* a zero in the slot padding is not payload */
+            }
+            const uint64_t hit = ballot64(first < 16u);
+            if (hit) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(hit);
+                const uint32_t f = (uint32_t)__shfl((int)first, (int)src);
+                eff = base + src * KMP_LANE_BYTES + f + 1u;
+                break;
+            }
+        }
+        acc += eff;
+    }
+    if (lane == 0u && acc) atomicAdd(out, acc);
+}
+}  // namespace
+
+hipError_t kmp_launch_effective_bytes(const uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n,
+                                      unsigned long long *out, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(kmp_effective_bytes_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, arena, pkt_off, pkt_len, n, out);
+    return hipGetLastError();
+}
+
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,
                                uint32_t *err, unsigned long long *payload_bytes, hipStream_t st)
 {

@@ -918,6 +918,24 @@ int kmpgpu_arena_info(kmpgpu_ctx *c, uint64_t *n_pkts, uint64_t *payload_bytes)
     return KMPGPU_OK;
 }
 
+int kmpgpu_effective_bytes(kmpgpu_ctx *c, uint64_t *bytes_out)
+{
+    if (!c || !bytes_out) return fail(KMPGPU_EINVAL, "kmpgpu_effective_bytes: NULL argument");
+    *bytes_out = 0;
+    if (c->n_pkts == 0) return KMPGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long *d = nullptr, h = 0ull;
+    HIP_TRY(hipMalloc(&d, sizeof h));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof h, c->stream);
+    if (e == hipSuccess) e = kmp_launch_effective_bytes(c->d_arena, c->d_off, c->d_len, c->n_pkts, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(KMPGPU_EHIP, "kmpgpu_effective_bytes: %s", hipGetErrorString(e));
+    *bytes_out = h;
+    return KMPGPU_OK;
+}
+
 int kmpgpu_arena_download(kmpgpu_ctx *c, uint8_t *arena_out, uint64_t arena_cap, uint64_t *arena_bytes, uint64_t *pkt_off_out,
                           uint32_t *pkt_len_out)
 {

@@ -113,6 +113,13 @@ class GpuMatcher:
         gpu_check(self._g.kmpgpu_arena_info(self._ctx, C.byref(n), C.byref(b)), "kmpgpu_arena_info")
         return int(n.value), int(b.value)
 
+    def effective_bytes(self) -> int:
+        """Sum over payloads of min(len, first NUL + 1): what a strlen()-bounded scan (serial.c:191) has to
+        touch; equals the payload bytes on NUL-free input."""
+        b = C.c_uint64()
+        gpu_check(self._g.kmpgpu_effective_bytes(self._ctx, C.byref(b)), "kmpgpu_effective_bytes")
+        return int(b.value)
+
     # -- the hot path -----------------------------------------------------------------------------
     def scan(self) -> Tuple[np.ndarray, Timing]:
         """Per-pattern counts (uint64, pattern order) and the timing of this pass."""

@@ -715,6 +715,82 @@ def test_device_extraction_crafted_frames(gm, kat_extract, tmp_path):
         _same_arena(gm, host)
 
 
+def _effective_bytes_np(payloads):
+    tot = 0
+    for b in payloads:
+        z = b.find(b"\x00")
+        tot += len(b) if z < 0 else z + 1
+    return tot
+
+
+def test_effective_bytes(gm):
+    """for NUL-laden input report the bytes up to the first NUL beside the payload bytes."""
+    rng = random.Random(12)
+    payloads = []
+    for k in range(700):
+        L = rng.choice([0, 1, 15, 16, 17, 100, 1023, 1024, 1025, 1500, 4000])
+        b = bytearray(rng.randrange(1, 256) for _ in range(L))
+        r = rng.random()
+        if L and r < 0.2:
+            b[0] = 0
+        elif L and r < 0.4:
+            b[L - 1] = 0
+        elif L and r < 0.7:
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(L)] = 0
+        payloads.append(bytes(b))
+    gm.load_arena(K.HostArena.from_payloads(payloads))
+    assert gm.arena_info() == (len(payloads), sum(map(len, payloads)))
+    assert gm.effective_bytes() == _effective_bytes_np(payloads)
+    gm.load_arena(K.HostArena.from_payloads([b"abc", b"", b"zz"]))
+    assert gm.effective_bytes() == 5
+    gm.load_arena(K.HostArena.from_payloads([]))
+    assert gm.effective_bytes() == 0
+
+
+def test_cli_stats_line(fixture_counts):
+    fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
+    arena = K.HostArena.from_pcap(os.path.join(DATA, fx["pcap"]), "udp")
+    want = _effective_bytes_np([arena.payload(k) for k in range(arena.n_pkts)])
+    for extra_env in ({}, {"KMPGPU_DEVICE_EXTRACT": "1"}):
+        env = dict(os.environ, KMPGPU_STATS="1", **extra_env)
+        r = subprocess.run([os.path.join(_lib.BINDIR, "serial"), os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt")],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert f"[kmpgpu] {want} of the {arena.payload_bytes} payload bytes lie at or before the first NUL" in r.stderr, r.stderr
+
+
+def test_border_rich_pattern_two_letter_text(gm, oracle):
+    """SURVEY 8(d) S1 stress variant: 'abababababababab' (failure table 0,0,1,2,...,14) planted in text over {a, b}:
+    overlapping occurrences and long partial matches at every alignment, all kernels."""
+    needle = b"ab" * 8
+    sp = K.SynthParams.make(seed=99, needle=needle, plant_permille=400, lo=ord("a"), span=2)
+    n, L = 4000, 1500
+    d_arena, d_off, d_len, off, ln, nbytes = _device_synth(gm, n, L, sp)
+    host = d_arena.cpu().numpy()
+    # long runs of the period, so that matches overlap (the generator plants the needle once per packet at most)
+    view = host
+    rng = np.random.default_rng(8)
+    for k in rng.choice(n, size=600, replace=False):
+        s0 = int(off[k]) + int(rng.integers(0, L - 400)); run = int(rng.integers(17, 400))
+        view[s0:s0 + run] = np.frombuffer((b"ab" * 200)[:run], dtype=np.uint8)
+    pats = [needle, b"ba" * 8, b"abab", b"aba", b"bb", b"a" * 16]
+    want, _ = oracle.count(host, off, ln, pats, threads=8)
+    assert want[0] > 600 * 10
+    import torch
+    d2 = torch.from_numpy(host).cuda()
+    gm.set_patterns(pats)
+    gm.attach_arena(d2, d_off, d_len)
+    for mode, kernel in VARIANTS:
+        gm.set_option(OPT_MODE, mode)
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
+        gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
+        got, _ = gm.scan()
+        assert got.tolist() == want.tolist(), (mode, kernel)
+    gm.set_option(OPT_MODE, MODE_FILTER); gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
+    gm.set_stream(None)
+
+
 def test_cli_device_extraction(fixture_counts, tokens):
     env = dict(os.environ, KMPGPU_DEVICE_EXTRACT="1")
     for key, prog, extra in (("big_udp.pcap:udp", "serial", []), ("udp_1000.pcap:tcp", "serial", []), ("big_udp.pcap:udp", "openmp_data", ["3"])):
