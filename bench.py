@@ -74,6 +74,8 @@ def main() -> None:
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: create the process group and run the all-reduce path "
+                    "even with one rank (checks the RCCL plumbing on a 1-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -100,8 +102,10 @@ def main() -> None:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -145,37 +149,46 @@ def main() -> None:
         raise SystemExit(f"rank {rank}: GPU count {int(got[0])} != planted {planted}")
 
     # ---- timed region -----------------------------------------------------------------------------
-    ring = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(4)]
-    works = [None] * len(ring)
+    # The only exchange of the path is the SUM of the per-pattern counters (mpi_dumping.c:202).  Step i leaves
+    # its counter in slot i % G of one of two device buffers; a full buffer is all-reduced in ONE collective
+    # (G x 8 bytes) while the next G steps fill the other buffer: fewer, larger collectives, none of them on
+    # the scan stream's critical path.
+    G = 4
+    bufs = [torch.zeros(G, dtype=torch.int64, device=dev) for _ in range(2)]
+    works = [None, None]
 
     def step(i):
-        slot = i % len(ring)
-        if works[slot] is not None:
-            works[slot].wait()                 # the buffer's previous all-reduce has finished
-            works[slot] = None
-        m.scan_enqueue(ring[slot])             # scan kernel + partial reduce -> ring[slot] (device)
-        if world > 1:                          # mpi_dumping.c:202, overlapped with the next step's scan
-            works[slot] = dist.all_reduce(ring[slot], op=dist.ReduceOp.SUM, async_op=True)
+        b, j = (i // G) % 2, i % G
+        if j == 0 and works[b] is not None:
+            works[b].wait()                    # this buffer's previous all-reduce has finished (stream-side wait)
+            works[b] = None
+        m.scan_enqueue(bufs[b][j:j + 1])       # scan kernel + partial reduce -> the slot (device memory)
+        if use_dist and j == G - 1:
+            works[b] = dist.all_reduce(bufs[b], op=dist.ReduceOp.SUM, async_op=True)
 
-    def drain():
-        for s, w in enumerate(works):
+    def drain(n_steps):
+        """Reduce the buffer the last steps left partly filled, then wait for everything."""
+        if use_dist and n_steps % G:
+            b = (n_steps // G) % 2
+            works[b] = dist.all_reduce(bufs[b], op=dist.ReduceOp.SUM, async_op=True)
+        for b, w in enumerate(works):
             if w is not None:
                 w.wait()
-                works[s] = None
+                works[b] = None
 
     for i in range(args.settle):               # device settle-in, not part of W or K
-        m.scan_enqueue(ring[0])
+        m.scan_enqueue(bufs[0][0:1])
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    drain()
+    drain(args.warmup)
     kd.barrier()
     torch.cuda.synchronize()
     m.profile_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain()
+    drain(args.steps)
     torch.cuda.synchronize()
     kd.barrier()
     t1 = time.perf_counter()
@@ -183,9 +196,10 @@ def main() -> None:
     elapsed = kd.max_over_ranks(t1 - t0, device=dev)
     avg_launch_ms = kd.max_over_ranks(float(launch_ms.mean()) if len(launch_ms) else 0.0, device=dev)
 
-    total = int(ring[(args.steps - 1) % len(ring)].item())
+    last = args.steps - 1
+    total = int(bufs[(last // G) % 2][last % G].item())
     planted_all = planted
-    if world > 1:
+    if use_dist:
         t = torch.tensor([planted], dtype=torch.int64, device=dev)
         kd.reduce_counts(t)
         planted_all = int(t.item())
@@ -259,7 +273,7 @@ def main() -> None:
         print(json.dumps(out), flush=True)
 
     m.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@ def reduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
     (MPI_Reduce(..., MPI_SUM, 0, ...) at mpi_dumping.c:202, as an all-reduce)."""
     if counts.dtype != torch.int64:
         raise TypeError("counts must be int64")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return counts
 
@@ -40,11 +40,11 @@ def reduce_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
 def max_over_ranks(value: float, device="cpu", group=None) -> float:
     """MPI_Reduce(&local_elapsed, &elapsed, 1, MPI_DOUBLE, MPI_MAX ...) at mpi_dumping.c:206."""
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
 def barrier(group=None) -> None:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier(group=group)
