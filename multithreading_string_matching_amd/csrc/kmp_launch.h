@@ -28,6 +28,7 @@ struct kmp_scan_args {
     /* packed kernel only */
     const unsigned long long *bitmap;   /* one bit per 16-byte slot of the arena: a payload starts here */
     const void            *plan;         /* kmp_plan_entry[waves + 1]                                   */
+    bool                   pad_clean;    /* every byte between a payload's end and the next slot is 0x00 */
     /* match-offset emission (streaming kernels only): kmpgpu_match[emit_cap], running counter */
     void                  *emit_out;
     unsigned long long    *emit_counter;
@@ -53,6 +54,8 @@ hipError_t kmp_launch_extract_phase2(const uint8_t *file, const uint64_t *frame_
 hipError_t kmp_launch_repack_phase1(const uint32_t *pkt_len, uint64_t n, uint8_t *ws, unsigned long long *totals, hipStream_t st);
 hipError_t kmp_launch_repack_phase2(const uint8_t *old_arena, const uint64_t *old_off, const uint32_t *pkt_len, uint64_t n, uint8_t *ws,
                                     uint8_t *new_arena, uint64_t *new_off, hipStream_t st);
+hipError_t kmp_launch_check_padding(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, int fix,
+                                    uint32_t *dirty, hipStream_t st);
 hipError_t kmp_launch_effective_bytes(const uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n,
                                       unsigned long long *out, hipStream_t st);
 hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t arena_bytes,

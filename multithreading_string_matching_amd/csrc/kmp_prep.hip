@@ -353,6 +353,48 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
     return hipGetLastError();
 }
 
+/* Packed arenas: are the bytes between a payload's end and the end of its 16-byte-padded slot all 0x00?  The
+ * host library, the device extraction and the repack write them so.  When they are, "the match window lies
+ * inside the payload" equals "it lies inside the slot and holds no 0x00" (patterns are NUL-free), and the
+ * packed kernel needs neither the payload's offset nor its length: the packet-start bitmap bounds the slot.
+ * fix != 0 (arena owned by the context): clear what is not. */
+namespace {
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_check_padding_kernel(uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len,
+                         uint64_t n, int fix, uint32_t *__restrict__ dirty)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t L = pkt_len[k], r = L & 15u;
+        if (L != 0u && r == 0u) continue;                               /* the payload fills its slot */
+        uint4 *g = reinterpret_cast<uint4 *>(arena + pkt_off[k] + (L - r));      /* last 16-byte group of the slot */
+        uint4 v = *g;
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t bad = 0u;
+#pragma unroll
+        for (uint32_t d = 0; d < 4u; ++d) {
+            const uint32_t lo = 4u * d;                                  /* payload bytes of this dword: [lo, r) */
+            const uint32_t keep = (r >= lo + 4u) ? 0xFFFFFFFFu : (r <= lo) ? 0u : ((1u << (8u * (r - lo))) - 1u);
+            bad |= w[d] & ~keep;
+            w[d] &= keep;
+        }
+        if (bad) {
+            atomicOr(dirty, 1u);
+            if (fix) *g = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+}  // namespace
+
+hipError_t kmp_launch_check_padding(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, int fix,
+                                    uint32_t *dirty, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(kmp_check_padding_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, arena, pkt_off, pkt_len, n, fix, dirty);
+    return hipGetLastError();
+}
+
 /* Sum over packets of min(len, first 0x00 + 1): the bytes a strlen()-bounded scan (serial.c:191) has to
  * touch.  One wavefront per packet, 1 KiB per step; SURVEY 8(d) asks for this figure beside the payload
  * bytes when the input carries NUL bytes.  Not on the hot path (one pass, on request). */

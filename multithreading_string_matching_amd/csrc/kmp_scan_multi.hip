@@ -27,7 +27,7 @@ namespace {
  *     registers, pattern records from LDS), check window-in-payload and the strlen() rule, and bump
  *     the pattern's counter in LDS.  Counters go to partials[unique pattern][block] at the end.
  * ============================================================================================== */
-template <int DEPTH, bool NT>
+template <int DEPTH, bool NT, bool CLEAN>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
@@ -116,17 +116,33 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     if (zl == 0ull) { if (st != 0ull) dead = false; }
                     else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
 
-                    /* payload bytes left from this lane's first byte (<= 0: slot padding) */
-                    int32_t rem = remc - (int32_t)vo0;
-                    int32_t remn = remc - (int32_t)KMP_CHUNK;
-                    for (uint64_t sb = st; sb != 0ull; sb &= sb - 1ull) {
-                        const uint32_t sl = (uint32_t)__builtin_ctzll(sb);
-                        ++kcur;
-                        const int32_t top = (int32_t)pkt_len[kcur] + (int32_t)(sl * KMP_LANE_BYTES);
-                        if (lane >= sl) rem = top - (int32_t)vo0;
-                        remn = top - (int32_t)KMP_CHUNK;
+                    /* rem: payload bytes left from this lane's first byte */
+                    int32_t rem;
+                    if constexpr (CLEAN) {
+                        /* Slot padding is all 0x00 (kmp_check_padding_kernel), so the payload's end can be replaced by
+                         * the slot's end: a window that reaches into the padding holds a 0x00 and matches nothing.
+                         * Only lanes within 2 x 16 bytes of the next packet start are constrained (patterns are at
+                         * most 20 bytes): two lane masks from the start bitmap, no payload lengths, no loop. */
+                        uint64_t nx;                                                /* start bits of the next chunk */
+                        if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
+                        else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
+                        const uint64_t sg = st_[s];                                 /* not cut at the range's end: the next wavefront's first start ends our last slot */
+                        const bool next1 = __builtin_amdgcn_inverse_ballot_w64((sg >> 1) | (nx << 63));     /* lane + 1 starts a packet */
+                        const bool next2 = __builtin_amdgcn_inverse_ballot_w64((sg >> 2) | (nx << 62));     /* lane + 2 does            */
+                        rem = next1 ? 16 : next2 ? 32 : (1 << 20);
+                    } else {
+                        /* from the index: uniform loop over the packet starts of the chunk (<= 0: slot padding) */
+                        rem = remc - (int32_t)vo0;
+                        int32_t remn = remc - (int32_t)KMP_CHUNK;
+                        for (uint64_t sb = st; sb != 0ull; sb &= sb - 1ull) {
+                            const uint32_t sl = (uint32_t)__builtin_ctzll(sb);
+                            ++kcur;
+                            const int32_t top = (int32_t)pkt_len[kcur] + (int32_t)(sl * KMP_LANE_BYTES);
+                            if (lane >= sl) rem = top - (int32_t)vo0;
+                            remn = top - (int32_t)KMP_CHUNK;
+                        }
+                        remc = remn;
                     }
-                    remc = remn;
 
                     /* level 1: which start offsets may begin some pattern (filter over the first three bytes)? */
                     uint32_t hm = 0u;
@@ -212,12 +228,11 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const size_t lds = ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
-    if (a.nontemporal)
-        hipLaunchKernelGGL((kmp_scan_multi_kernel<4, true>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, a.arena, a.pkt_len,
-                           a.bitmap, plan, tables, table_words, n_unique, a.partials);
-    else
-        hipLaunchKernelGGL((kmp_scan_multi_kernel<4, false>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, a.arena, a.pkt_len,
-                           a.bitmap, plan, tables, table_words, n_unique, a.partials);
+#define KMP_MULTI_LAUNCH(NT_, CLEAN_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
+        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, a.partials)
+    if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true); else KMP_MULTI_LAUNCH(false, true); }
+    else             { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false); else KMP_MULTI_LAUNCH(false, false); }
+#undef KMP_MULTI_LAUNCH
     return hipGetLastError();
 }
 

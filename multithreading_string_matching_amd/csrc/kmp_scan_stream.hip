@@ -192,7 +192,8 @@ __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
                        const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,
                        const kmp_plan_entry *__restrict__ plan, const kmp_pattern_dev *__restrict__ patterns,
-                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
+                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em,
+                       uint32_t pad_clean)
 {
     __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
@@ -285,7 +286,25 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                         int32_t  maxi = -1;
                         uint32_t p0 = 0u, L = 0u;
                         uint64_t kl = 0ull;
-                        if (fm == 0u) {
+                        if (!EMIT && pad_clean) {
+                            /* Slot padding is all 0x00 (checked when the arena was loaded), so "the window lies inside
+                             * the payload" = "it lies inside the slot and holds no 0x00": the distance to the next
+                             * packet start, read off the bitmap, replaces the payload's offset and length -- no
+                             * gather from the index, which costs a memory round trip per candidate chunk. */
+                            if (fm == 0u) {
+                                const uint64_t above = (st >> 1) >> lane;               /* starts at the lanes above own */
+                                uint32_t d = 4096u;                                     /* 16-byte groups up to the next start */
+                                if (above != 0ull) d = (uint32_t)__builtin_ctzll(above) + 1u;
+                                else {
+                                    uint64_t nx;                                        /* start bits of the next chunk */
+                                    if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
+                                    else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
+                                    if (nx != 0ull) d = 64u - lane + (uint32_t)__builtin_ctzll(nx);
+                                }
+                                L = d * KMP_LANE_BYTES;                                 /* bytes from the lane's first to the slot's end */
+                                maxi = (int32_t)L - (int32_t)m;
+                            }
+                        } else if (fm == 0u) {
                             const uint64_t le = (2ull << lane) - 1ull;                  /* lanes <= own (lane 63: all ones) */
                             kl = kbase + (uint64_t)__builtin_popcountll(st & le);
                             const uint64_t po = pkt_off[kl];
@@ -374,7 +393,7 @@ hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const Emitter em = emitter_of(a);
-#define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, em
+#define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, em, (a.pad_clean ? 1u : 0u)
     if (a.emit_out)
         hipLaunchKernelGGL((kmp_scan_packed_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_PACKED_ARGS);
     else if (a.nontemporal)

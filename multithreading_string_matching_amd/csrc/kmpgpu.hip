@@ -78,6 +78,7 @@ struct kmpgpu_ctx {
     uint64_t        arena_bytes = 0, n_pkts = 0, payload_bytes = 0;
     bool            uniform = false;                  /* every payload has the same length, slots back to back */
     bool            packed = false;                   /* slots back to back (any lengths): flat streaming with bitmap + plan */
+    bool            pad_clean = false;                /* packed arena whose slot padding is all 0x00 (kmp_check_padding_kernel) */
     uint64_t        span_end = 0;                     /* end offset of the last slot */
     unsigned long long *d_bitmap = nullptr;           /* one bit per 16-byte slot: a payload starts here */
     void           *d_plan = nullptr;                 /* kmp_plan_entry[plan_waves + 1] */
@@ -166,7 +167,7 @@ void release_arena(kmpgpu_ctx *c, bool keep_buffers = false)
     }
     c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
     c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
-    c->uniform = false; c->packed = false; c->plan_waves = 0;
+    c->uniform = false; c->packed = false; c->pad_clean = false; c->plan_waves = 0;
     if (c->d_bitmap) (void)hipFree(c->d_bitmap);
     c->d_bitmap = nullptr;
 }
@@ -221,7 +222,15 @@ int prepare_packed(kmpgpu_ctx *c)
     HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->d_bitmap, 0, words * sizeof(unsigned long long), c->stream));
     HIP_TRY(kmp_launch_build_bitmap(c->d_off, c->n_pkts, c->d_bitmap, c->stream));
+    /* slot padding: checked once; cleared when the arena is the context's own copy, otherwise the packed
+     * kernel keeps fetching offset and length of a candidate's payload from the index */
+    const bool own = c->owned_arena && c->d_arena == (const uint8_t *)c->owned_arena;
+    uint32_t dirty = 0;
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(kmp_launch_check_padding(const_cast<uint8_t *>(c->d_arena), c->d_off, c->d_len, c->n_pkts, own ? 1 : 0, c->d_err, c->stream));
+    HIP_TRY(hipMemcpyAsync(&dirty, c->d_err, sizeof dirty, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->pad_clean = own || dirty == 0;
     return KMPGPU_OK;
 }
 
@@ -247,6 +256,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     a.arena = c->d_arena; a.pkt_off = c->d_off; a.pkt_len = c->d_len; a.n_pkts = c->n_pkts;
     a.patterns = c->d_patterns; a.blocks_x = bx; a.depth = c->depth; /* 0: the launcher's own default */ a.mode = c->mode;
     a.nontemporal = c->nontemporal != 0;
+    a.pad_clean = c->pad_clean;
     if (emit) { a.emit_out = emit->out; a.emit_counter = emit->counter; a.emit_cap = emit->cap; }
     /* uniform-stride arenas take the flat streaming kernel (contiguous packet run per wavefront) */
     const uint64_t nwaves = (uint64_t)bx * KMP_BLOCK_WAVES;

@@ -438,6 +438,55 @@ def test_non_packed_arena(gm, oracle):
     gm.set_option(OPT_KERNEL, KERNEL_AUTO)
 
 
+@pytest.mark.parametrize("uniform", [False, True])
+def test_dirty_slot_padding(gm, oracle, uniform):
+    """The bytes between a payload's end and the end of its 16-byte slot need not be zero for the C-ABI.  Here they
+    continue the payload's own period, so a matcher that ignored the payload length would overcount.  An arena
+    the library copies (load_arena) gets its padding cleared on the device; a borrowed one (attach_arena) is
+    scanned with the lengths taken from the index."""
+    import torch
+    rng = random.Random(23)
+    pats = [b"abc", b"abcabcabcabc", b"ab", b"bca" * 7, b"c", b"cabca"]
+    lens = [100] * 400 if uniform else [rng.choice([0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 100, 200, 1000, 1030]) for _ in range(600)]
+    ln = np.array(lens, dtype=np.uint32)
+    slot = np.maximum(16, (ln.astype(np.uint64) + 15) // 16 * 16)
+    off = np.concatenate([[0], np.cumsum(slot)[:-1]]).astype(np.uint64)
+    nbytes = int(slot.sum()) + 64
+    arena = np.frombuffer((b"abc" * (nbytes // 3 + 1))[:nbytes], dtype=np.uint8).copy()      # payload k = its slice of the period
+    want, _ = oracle.count(arena, off, ln, pats)
+    clean = arena.copy()
+    for k in range(len(lens)):
+        clean[int(off[k]) + lens[k]:int(off[k] + slot[k])] = 0
+    clean[int(off[-1] + slot[-1]):] = 0
+    assert oracle.count(clean, off, ln, pats)[0].tolist() == want.tolist()
+    overcount, _ = oracle.count(arena, off, slot.astype(np.uint32), pats)
+    assert overcount.sum() > want.sum()                                                       # the trap is armed
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    variants = (KERNEL_AUTO, KERNEL_PACKED, KERNEL_FUSED, KERNEL_GENERAL)
+    try:
+        gm.load_arena(arena, off, ln)                         # the context's own copy: padding cleared in place
+        for kernel in variants:
+            gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
+            gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
+            assert gm.scan()[0].tolist() == want.tolist(), ("owned", kernel)
+        a2, off2, ln2 = gm.arena_download()
+        assert np.array_equal(a2[:int(off[-1] + slot[-1])], clean[:int(off[-1] + slot[-1])])
+        d_arena = torch.from_numpy(arena).cuda(); d_off = torch.from_numpy(off.astype(np.int64)).cuda(); d_len = torch.from_numpy(ln.astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        gm.attach_arena(d_arena, d_off, d_len)                # borrowed: left as it is
+        for kernel in variants:
+            gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
+            gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
+            assert gm.scan()[0].tolist() == want.tolist(), ("borrowed", kernel)
+        assert np.array_equal(d_arena.cpu().numpy(), arena)
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 0)
+        recs, found, cnts = gm.scan_offsets(int(want.sum()) + 10)
+        assert found == int(want.sum()) and cnts.tolist() == want.tolist()
+    finally:
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
+
+
 def test_layout_contract_is_checked(gm):
     gm.set_patterns([b"http"])
     a = np.zeros(256, dtype=np.uint8)
