@@ -113,7 +113,10 @@ int  kmpgpu_set_patterns(kmpgpu_ctx *ctx, const uint8_t *const *pat, const uint3
 /* Replaces array_of_payloads, serial.c:99,124-136: upload a host arena + index (H2D copy,
  * device copy owned by the context).  Contract: pkt_off[k] % 16 == 0 and
  * pkt_off[k] + max(16, round_up(pkt_len[k], 16)) <= arena_bytes for every k (checked): every
- * payload, also an empty one, owns at least one readable 16-byte slot. */
+ * payload, also an empty one, owns at least one readable 16-byte slot.  The bytes between a payload's
+ * end and the end of its slot may hold anything; when they are 0x00 (as kmp_arena builds them -- checked
+ * at load time, and cleared in the copy kmpgpu_load_arena makes) the streaming kernels take a payload's
+ * end from the packet-start bitmap and never read the index on the scan path. */
 int  kmpgpu_load_arena(kmpgpu_ctx *ctx, const uint8_t *arena, uint64_t arena_bytes,
                        const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n_pkts);
 
