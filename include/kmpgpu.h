@@ -67,12 +67,13 @@ typedef struct kmpgpu_match {
                                         bytes is counted in ONE read of a packed arena (the
                                         others keep one read per pattern); 0 = off; 2 = auto
                                         (default): fused from 3 such unique patterns on       */
-#define KMPGPU_OPT_KERNEL        5   /* 0 auto: flat streaming kernel when every payload has the
-                                        same length and the slots are back to back, packed
-                                        streaming kernel when the slots are back to back with
-                                        mixed lengths, else the general kernel; 1 always the
-                                        general one-packet-per-wavefront kernel; 2 the packed
-                                        streaming kernel whenever the slots are back to back   */
+#define KMPGPU_OPT_KERNEL        5   /* 0 auto: slots back to back -> packed streaming kernel, or
+                                        the flat streaming kernel when every payload has the same
+                                        length of 512 bytes or more (also taken for equal slots
+                                        with gaps between them); otherwise the general kernel.
+                                        1 always the general one-packet-per-wavefront kernel;
+                                        2 the packed kernel whenever the slots are back to back;
+                                        3 the flat kernel whenever the stride is uniform          */
 
 #define KMPGPU_OPT_ACCUMULATE    6   /* 1 = every pass ADDS to the counts buffer instead of
                                         overwriting it (batches of a streamed capture,

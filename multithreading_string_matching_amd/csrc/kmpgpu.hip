@@ -110,7 +110,14 @@ struct kmpgpu_ctx {
 
 namespace {
 
-bool use_flat(const kmpgpu_ctx *c) { return c->uniform && c->kernel_sel == 0 && c->mode == 0; }
+/* Uniform-stride arenas: the flat kernel from 512-byte payloads on; below that a chunk holds several packets and
+ * the packed kernel's bitmap beats the flat kernel's arithmetic by 3-6 % (profiles/r01_flat_vs_packed.txt). */
+bool use_flat(const kmpgpu_ctx *c)
+{
+    if (!c->uniform || c->mode != 0) return false;
+    if (c->kernel_sel == 3) return true;
+    return c->kernel_sel == 0 && (c->uni_len >= 512u || !c->packed || !c->d_bitmap);
+}
 /* Fused multi-pattern pass: explicit (1) or automatic (2: from 3 unique eligible patterns on, where it
  * beats one streaming pass per pattern -- profiles/r01_multipattern.txt). */
 bool use_fused(const kmpgpu_ctx *c)
@@ -122,7 +129,7 @@ bool use_fused(const kmpgpu_ctx *c)
 
 bool use_packed(const kmpgpu_ctx *c)
 {
-    return c->packed && c->d_bitmap && c->mode == 0 && (c->kernel_sel == 2 || (c->kernel_sel == 0 && !c->uniform));
+    return c->packed && c->d_bitmap && c->mode == 0 && (c->kernel_sel == 2 || ((c->kernel_sel == 0 || c->kernel_sel == 3) && !use_flat(c)));
 }
 
 uint32_t grid_blocks(const kmpgpu_ctx *c)
@@ -445,7 +452,7 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
     case KMPGPU_OPT_ACCUMULATE:
         c->accumulate = value ? 1 : 0; return KMPGPU_OK;
     case KMPGPU_OPT_KERNEL:
-        if (value < 0 || value > 2) return fail(KMPGPU_EINVAL, "kernel selection must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(KMPGPU_EINVAL, "kernel selection must be 0, 1, 2 or 3");
         c->kernel_sel = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_NONTEMPORAL:
         c->nontemporal = value ? 1 : 0; return KMPGPU_OK;
@@ -861,7 +868,7 @@ int kmpgpu_scan_offsets(kmpgpu_ctx *c, kmpgpu_match *out, uint64_t cap, uint64_t
 {
     if (!c || !n_found) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: NULL argument");
     if (cap && !out) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: out is NULL");
-    if (c->mode != 0 || c->kernel_sel == 1) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets runs on the streaming kernels only (mode 0, kernel 0 or 2)");
+    if (c->mode != 0 || c->kernel_sel == 1) return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets runs on the streaming kernels only (mode 0, kernel 0, 2 or 3)");
     static_assert(sizeof(kmpgpu_match) == 16, "kmpgpu_match is a 16-byte record");
     HIP_TRY(hipSetDevice(c->device));
     *n_found = 0;

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 import multithreading_string_matching_amd as K  # noqa: E402
 from multithreading_string_matching_amd import _lib  # noqa: E402
 from multithreading_string_matching_amd.matcher import (  # noqa: E402
-    KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_MODE,
+    KERNEL_AUTO, KERNEL_FLAT, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_MODE,
     OPT_NONTEMPORAL, GpuMatcher)
 
 FIXTURE_KEYS = [
@@ -52,7 +52,7 @@ def gpu_counts(gm, patterns, arena, mode=MODE_FILTER, depth=0, kernel=KERNEL_AUT
 # (mode, kernel): filter+confirm on the auto-selected kernel (flat streaming for uniform-length
 # arenas, packed streaming for mixed lengths), the packed streaming kernel forced, the general
 # one-packet-per-wavefront kernel forced, and the pure KMP automaton.
-VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED), (MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_GENERAL),
+VARIANTS = ((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_FLAT), (MODE_FILTER, KERNEL_PACKED), (MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_GENERAL),
             (MODE_AUTOMATON, KERNEL_GENERAL))
 
 
@@ -190,7 +190,7 @@ def test_uniform_length_arenas_with_nuls(gm, oracle, L):
         payloads.append(bytes(b))
     check_payloads(gm, oracle, payloads, pats)
     for depth in (2, 3, 4, 5, 6, 8):
-        check_payloads(gm, oracle, payloads[:97], pats[:3], variants=((MODE_FILTER, KERNEL_AUTO), (MODE_FILTER, KERNEL_PACKED)), depth=depth)
+        check_payloads(gm, oracle, payloads[:97], pats[:3], variants=((MODE_FILTER, KERNEL_FLAT), (MODE_FILTER, KERNEL_PACKED)), depth=depth)
 
 
 def test_uniform_length_few_packets(gm, oracle):
