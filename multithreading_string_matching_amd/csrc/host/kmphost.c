@@ -7,8 +7,12 @@
 #include "kmphost.h"
 
 #include <errno.h>
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -16,161 +20,233 @@
 /* ============================ pcap savefile reader =====================================
  * What the reference obtains from libpcap: pcap_open_offline (serial.c:91), pcap_next_ex
  * (serial.c:115).  Classic pcap: 24-byte global header {magic, ver_major, ver_minor, thiszone,
- * sigfigs, snaplen, linktype}, then records {ts_sec, ts_frac, caplen, len} + caplen bytes. */
-struct kmp_pcap {
-    FILE    *fp;
-    int      swap;          /* file byte order differs from the host's */
-    int      ng;            /* pcapng (libpcap's pcap_open_offline reads both formats) */
-    uint32_t linktype;
-    uint32_t snaplen;
-    uint8_t *buf;
-    size_t   cap;
-};
+ * sigfigs, snaplen, linktype}, then records {ts_sec, ts_frac, caplen, len} + caplen bytes.
+ *
+ * The file is mapped, not read: records are handed out (and copied from, by several threads) in
+ * place.  One walker serves the record reader, the arena builder, the frame index of the on-device
+ * extraction and the batch producer, so that all of them end at the same record of a damaged file. */
+typedef struct kmp_view {
+    const uint8_t *base;
+    uint64_t       size;
+    int            mapped;       /* 1: munmap, 0: free (fallback for what cannot be mapped, e.g. a pipe) */
+} kmp_view;
+
+static int view_open(const char *path, kmp_view *v, char errbuf[KMP_PCAP_ERRBUF])
+{
+    memset(v, 0, sizeof *v);
+    if (errbuf) errbuf[0] = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: %s", path, strerror(errno));
+        return KMPHOST_EIO;
+    }
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+        v->size = (uint64_t)st.st_size;
+        if (v->size) {
+            void *m = mmap(NULL, (size_t)v->size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)v->size, MADV_WILLNEED);
+                v->base = (const uint8_t *)m; v->mapped = 1;
+                close(fd);
+                return KMPHOST_OK;
+            }
+        } else { close(fd); return KMPHOST_OK; }
+    }
+    /* not mappable: read it */
+    size_t cap = 1u << 20, n = 0;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    for (;;) {
+        if (!buf) { close(fd); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return KMPHOST_ENOMEM; }
+        const ssize_t got = read(fd, buf + n, cap - n);
+        if (got < 0) { if (errno == EINTR) continue; free(buf); close(fd); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: %s", path, strerror(errno)); return KMPHOST_EIO; }
+        if (got == 0) break;
+        n += (size_t)got;
+        if (n == cap) { cap *= 2; uint8_t *nb = (uint8_t *)realloc(buf, cap); if (!nb) free(buf); buf = nb; }
+    }
+    close(fd);
+    v->base = buf; v->size = n; v->mapped = 0;
+    return KMPHOST_OK;
+}
+
+static void view_close(kmp_view *v)
+{
+    if (v->base) { if (v->mapped) munmap((void *)v->base, (size_t)v->size); else free((void *)v->base); }
+    memset(v, 0, sizeof *v);
+}
+
+/* Worker threads for the copy loops: the CPUs this process may use (affinity, cgroup quota), at most 16 --
+ * a memcpy stream per core saturates the memory system well before that. */
+static int host_threads(void)
+{
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 1;
+#ifdef _OPENMP
+    n = omp_get_num_procs();
+#endif
+    FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (fp) {
+        char q[32]; long period = 0;
+        if (fscanf(fp, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0 && (quota + period - 1) / period < n) n = (int)((quota + period - 1) / period);
+        }
+        fclose(fp);
+    } else {
+        long quota = -1, period = 0;
+        FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fpd = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fpd && fscanf(fq, "%ld", &quota) == 1 && fscanf(fpd, "%ld", &period) == 1 && quota > 0 && period > 0 &&
+            (quota + period - 1) / period < n) n = (int)((quota + period - 1) / period);
+        if (fq) fclose(fq);
+        if (fpd) fclose(fpd);
+    }
+    const char *e = getenv("KMPHOST_THREADS");
+    if (e && atoi(e) > 0) n = atoi(e);
+    if (n > 16 && !(e && atoi(e) > 0)) n = 16;
+    if (n < 1) n = 1;
+    cached = n;
+    return n;
+}
 
 #define PCAPNG_SHB 0x0A0D0D0Au
 #define PCAPNG_BOM 0x1A2B3C4Du
 
 static uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
-kmp_pcap *kmp_pcap_open(const char *path, char errbuf[KMP_PCAP_ERRBUF])
+typedef struct kmp_walk {
+    const uint8_t *b;
+    uint64_t sz, pos;
+    int      swap;          /* file byte order differs from the host's */
+    int      ng;            /* pcapng (libpcap's pcap_open_offline reads both formats) */
+    uint32_t linktype, snaplen;
+} kmp_walk;
+
+/* The checks pcap_open_offline makes on the file header (message texts as libpcap words them). */
+static int walk_init(kmp_walk *w, const uint8_t *b, uint64_t sz, char errbuf[KMP_PCAP_ERRBUF])
 {
-    if (errbuf) errbuf[0] = 0;
-    FILE *fp = fopen(path, "rb");
-    if (!fp) {
-        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: %s", path, strerror(errno));
-        return NULL;
+    memset(w, 0, sizeof *w);
+    w->b = b; w->sz = sz;
+    if (sz < 24u) {
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "truncated dump file; tried to read %zu file header bytes", (size_t)24);
+        return KMPHOST_EIO;
     }
-    uint32_t h[6];
-    if (fread(h, 1, sizeof h, fp) != sizeof h) {
-        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "truncated dump file; tried to read %zu file header bytes", sizeof h);
-        fclose(fp);
-        return NULL;
-    }
-    int swap, ng = 0;
-    if (h[0] == 0xA1B2C3D4u || h[0] == 0xA1B23C4Du) swap = 0;
-    else if (bswap32(h[0]) == 0xA1B2C3D4u || bswap32(h[0]) == 0xA1B23C4Du) swap = 1;
-    else if (h[0] == PCAPNG_SHB && (h[2] == PCAPNG_BOM || bswap32(h[2]) == PCAPNG_BOM)) { ng = 1; swap = (h[2] != PCAPNG_BOM); }
+    const uint32_t magic = rd32(b), bom = rd32(b + 8);
+    if (magic == 0xA1B2C3D4u || magic == 0xA1B23C4Du) w->swap = 0;
+    else if (bswap32(magic) == 0xA1B2C3D4u || bswap32(magic) == 0xA1B23C4Du) w->swap = 1;
+    else if (magic == PCAPNG_SHB && (bom == PCAPNG_BOM || bswap32(bom) == PCAPNG_BOM)) { w->ng = 1; w->swap = (bom != PCAPNG_BOM); }
     else {
         if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "unknown file format");
-        fclose(fp);
-        return NULL;
+        return KMPHOST_EFORMAT;
     }
-    kmp_pcap *p = (kmp_pcap *)calloc(1, sizeof *p);
-    if (!p) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
-    p->fp = fp;
-    p->swap = swap;
-    p->ng = ng;
-    if (ng) {
-        p->snaplen = 0; p->linktype = 1;
-        fseek(fp, 0, SEEK_SET);                     /* the block walker starts at the section header */
-    } else {
-        p->snaplen = swap ? bswap32(h[4]) : h[4];
-        p->linktype = swap ? bswap32(h[5]) : h[5];
+    if (w->ng) { w->snaplen = 0; w->linktype = 1; w->pos = 0; }      /* the block walker starts at the section header */
+    else {
+        w->snaplen = w->swap ? bswap32(rd32(b + 16)) : rd32(b + 16);
+        w->linktype = w->swap ? bswap32(rd32(b + 20)) : rd32(b + 20);
+        w->pos = 24;
     }
-    return p;
+    return KMPHOST_OK;
 }
 
-/* One pcapng block body in p->buf -> a packet?  Returns 1 and the packet, or 0 for other blocks. */
-static int pcapng_packet(kmp_pcap *p, uint32_t type, uint32_t body, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+/* One pcapng block body -> a packet?  1 and the packet, 0 for other blocks, -1 for a damaged one. */
+static int pcapng_packet(kmp_walk *w, uint32_t type, uint32_t body, const uint8_t *b, uint32_t *caplen, uint32_t *len, const uint8_t **data)
 {
-    const uint8_t *b = p->buf;
-    uint32_t w[5];
-    if (type == 6u && body >= 20u) {                 /* Enhanced Packet Block */
-        memcpy(w, b, 20);
-        const uint32_t cl = p->swap ? bswap32(w[3]) : w[3], ln = p->swap ? bswap32(w[4]) : w[4];
+    if ((type == 6u || type == 2u) && body >= 20u) {   /* Enhanced Packet Block / obsolete Packet Block */
+        const uint32_t cl = w->swap ? bswap32(rd32(b + 12)) : rd32(b + 12), ln = w->swap ? bswap32(rd32(b + 16)) : rd32(b + 16);
         if (cl > body - 20u) return -1;
         *caplen = cl; *len = ln; *data = b + 20;
         return 1;
     }
-    if (type == 2u && body >= 20u) {                 /* obsolete Packet Block */
-        memcpy(w, b, 20);
-        const uint32_t cl = p->swap ? bswap32(w[3]) : w[3], ln = p->swap ? bswap32(w[4]) : w[4];
-        if (cl > body - 20u) return -1;
-        *caplen = cl; *len = ln; *data = b + 20;
-        return 1;
-    }
-    if (type == 3u && body >= 4u) {                  /* Simple Packet Block */
-        memcpy(w, b, 4);
-        const uint32_t ln = p->swap ? bswap32(w[0]) : w[0];
+    if (type == 3u && body >= 4u) {                    /* Simple Packet Block */
+        const uint32_t ln = w->swap ? bswap32(rd32(b)) : rd32(b);
         uint32_t cl = ln;
-        if (p->snaplen && cl > p->snaplen) cl = p->snaplen;
+        if (w->snaplen && cl > w->snaplen) cl = w->snaplen;
         if (cl > body - 4u) cl = body - 4u;
         *caplen = cl; *len = ln; *data = b + 4;
         return 1;
     }
-    if (type == 1u && body >= 8u) {                  /* Interface Description Block: link type + snaplen of interface 0 */
+    if (type == 1u && body >= 8u) {                    /* Interface Description Block: link type + snaplen of interface 0 */
         uint16_t lt;
         memcpy(&lt, b, 2);
-        memcpy(w, b + 4, 4);
-        if (p->snaplen == 0) {
-            p->linktype = p->swap ? (uint32_t)((lt >> 8) | ((lt & 0xFF) << 8)) : lt;
-            p->snaplen = p->swap ? bswap32(w[0]) : w[0];
+        if (w->snaplen == 0) {
+            w->linktype = w->swap ? (uint32_t)((lt >> 8) | ((lt & 0xFF) << 8)) : lt;
+            w->snaplen = w->swap ? bswap32(rd32(b + 4)) : rd32(b + 4);
         }
     }
     return 0;
 }
 
-static int pcapng_next(kmp_pcap *p, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+/* pcap_next_ex: 1 = packet (data points into the file), -2 = end of file, -1 = truncated / damaged record. */
+static int walk_next(kmp_walk *w, uint32_t *caplen, uint32_t *len, const uint8_t **data)
 {
+    if (!w->ng) {
+        if (w->pos >= w->sz) return -2;                 /* clean end of file */
+        if (w->sz - w->pos < 16u) return -1;            /* truncated record header */
+        const uint8_t *r = w->b + w->pos;
+        const uint32_t cl = w->swap ? bswap32(rd32(r + 8)) : rd32(r + 8);
+        const uint32_t ln = w->swap ? bswap32(rd32(r + 12)) : rd32(r + 12);
+        if (cl > (64u << 20)) return -1;                /* corrupt record */
+        if (w->sz - w->pos - 16u < cl) return -1;       /* truncated packet */
+        *caplen = cl; *len = ln; *data = r + 16;
+        w->pos += 16u + (uint64_t)cl;
+        return 1;
+    }
     for (;;) {
-        uint32_t hd[2];
-        size_t got = fread(hd, 1, sizeof hd, p->fp);
-        if (got == 0) return -2;
-        if (got != sizeof hd) return -1;
-        uint32_t type = hd[0], total = hd[1];
-        if (type == PCAPNG_SHB) {                    /* a new section may change the byte order */
-            uint32_t bom;
-            if (fread(&bom, 1, 4, p->fp) != 4) return -1;
-            if (bom == PCAPNG_BOM) p->swap = 0;
-            else if (bswap32(bom) == PCAPNG_BOM) p->swap = 1;
+        if (w->pos >= w->sz) return -2;
+        if (w->sz - w->pos < 8u) return -1;
+        const uint8_t *h = w->b + w->pos;
+        uint32_t type = rd32(h), total = rd32(h + 4);
+        if (type == PCAPNG_SHB) {                       /* a new section may change the byte order */
+            if (w->sz - w->pos < 12u) return -1;
+            const uint32_t bom = rd32(h + 8);
+            if (bom == PCAPNG_BOM) w->swap = 0;
+            else if (bswap32(bom) == PCAPNG_BOM) w->swap = 1;
             else return -1;
-            total = p->swap ? bswap32(total) : total;
-            if (total < 16u || (total & 3u) || fseek(p->fp, (long)total - 12, SEEK_CUR) != 0) return -1;
-            p->snaplen = 0;
+            total = w->swap ? bswap32(total) : total;
+            if (total < 16u || (total & 3u)) return -1;
+            w->pos += total;                            /* a section header that runs past the end ends the file cleanly, as a seek does */
+            w->snaplen = 0;
             continue;
         }
-        if (p->swap) { type = bswap32(type); total = bswap32(total); }
+        if (w->swap) { type = bswap32(type); total = bswap32(total); }
         if (total < 12u || (total & 3u) || total > (64u << 20)) return -1;
         const uint32_t body = total - 12u;
-        if (body + 4u > p->cap) {
-            uint8_t *nb = (uint8_t *)realloc(p->buf, (size_t)body + 4096u);
-            if (!nb) return -1;
-            p->buf = nb; p->cap = (size_t)body + 4096u;
-        }
-        if (fread(p->buf, 1, (size_t)body + 4u, p->fp) != (size_t)body + 4u) return -1;    /* body + trailing length */
-        const int r = pcapng_packet(p, type, body, caplen, len, data);
+        if (w->sz - w->pos - 8u < (uint64_t)body + 4u) return -1;      /* body + trailing length */
+        const int r = pcapng_packet(w, type, body, h + 8, caplen, len, data);
+        w->pos += total;
         if (r != 0) return r;
     }
 }
 
-int kmp_pcap_next(kmp_pcap *p, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+struct kmp_pcap {
+    kmp_view view;
+    kmp_walk walk;
+};
+
+kmp_pcap *kmp_pcap_open(const char *path, char errbuf[KMP_PCAP_ERRBUF])
 {
-    if (p->ng) return pcapng_next(p, caplen, len, data);
-    uint32_t r[4];
-    size_t got = fread(r, 1, sizeof r, p->fp);
-    if (got == 0) return -2;                    /* clean end of file */
-    if (got != sizeof r) return -1;             /* truncated record header */
-    uint32_t cl = p->swap ? bswap32(r[2]) : r[2];
-    uint32_t ln = p->swap ? bswap32(r[3]) : r[3];
-    if (cl > (64u << 20)) return -1;            /* corrupt record */
-    if (cl > p->cap) {
-        size_t nc = cl + 4096u;
-        uint8_t *nb = (uint8_t *)realloc(p->buf, nc);
-        if (!nb) return -1;
-        p->buf = nb; p->cap = nc;
+    kmp_pcap *p = (kmp_pcap *)calloc(1, sizeof *p);
+    if (!p) { if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
+    if (view_open(path, &p->view, errbuf) || walk_init(&p->walk, p->view.base, p->view.size, errbuf)) {
+        view_close(&p->view);
+        free(p);
+        return NULL;
     }
-    if (cl && fread(p->buf, 1, cl, p->fp) != cl) return -1;   /* truncated packet */
-    *caplen = cl; *len = ln; *data = p->buf;
-    return 1;
+    return p;
 }
 
-uint32_t kmp_pcap_linktype(const kmp_pcap *p) { return p->linktype; }
+int kmp_pcap_next(kmp_pcap *p, uint32_t *caplen, uint32_t *len, const uint8_t **data)
+{
+    return walk_next(&p->walk, caplen, len, data);
+}
+
+uint32_t kmp_pcap_linktype(const kmp_pcap *p) { return p->walk.linktype; }
 
 void kmp_pcap_close(kmp_pcap *p)
 {
     if (!p) return;
-    if (p->fp) fclose(p->fp);
-    free(p->buf);
+    view_close(&p->view);
     free(p);
 }
 
@@ -325,7 +401,7 @@ uint64_t kmp_arena_layout(const uint32_t *lens, uint32_t fixed_len, uint64_t n, 
     return pos + KMP_ARENA_SLACK;
 }
 
-static int arena_alloc(kmp_arena *a, uint64_t nbytes, uint64_t n, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn)
+static int arena_alloc(kmp_arena *a, uint64_t nbytes, uint64_t n, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn, int zero)
 {
     memset(a, 0, sizeof *a);
     a->free_fn = alloc_fn ? free_fn : free;
@@ -333,7 +409,7 @@ static int arena_alloc(kmp_arena *a, uint64_t nbytes, uint64_t n, kmp_alloc_fn a
     a->off = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
     a->len = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
     if (!a->bytes || !a->off || !a->len) { kmp_arena_free(a); return KMPHOST_ENOMEM; }
-    memset(a->bytes, 0, (size_t)nbytes);
+    if (zero) memset(a->bytes, 0, (size_t)nbytes);
     a->nbytes = nbytes;
     return KMPHOST_OK;
 }
@@ -350,7 +426,7 @@ int kmp_arena_from_payloads(const uint8_t *const *payloads, const uint32_t *lens
                             kmp_alloc_fn alloc_fn, kmp_free_fn free_fn, kmp_arena *out)
 {
     const uint64_t nbytes = kmp_arena_layout(lens, 0, n, KMP_SLOT_ALIGN, NULL, NULL);
-    int rc = arena_alloc(out, nbytes, n, alloc_fn, free_fn);
+    int rc = arena_alloc(out, nbytes, n, alloc_fn, free_fn, 1);
     if (rc) return rc;
     kmp_arena_layout(lens, 0, n, KMP_SLOT_ALIGN, out->off, out->len);
     for (uint64_t k = 0; k < n; k++) {
@@ -364,42 +440,102 @@ int kmp_arena_from_payloads(const uint8_t *const *payloads, const uint32_t *lens
 
 /* serial.c:115-141.  Two passes over the savefile: size the arena, then fill it, so the arena is
  * one allocation of the final size (it may be pinned memory). */
+/* Every record of the mapped file: where its captured bytes lie.  Sequential (a record's position depends on
+ * all the records before it), but it touches 16 bytes per record only. */
+typedef struct kmp_index { uint64_t *off; uint32_t *caplen; uint64_t n, cap; } kmp_index;
+
+static int index_push(kmp_index *ix, uint64_t off, uint32_t cl)
+{
+    if (ix->n == ix->cap) {
+        const uint64_t nc = ix->cap ? ix->cap * 2 : 1u << 16;
+        uint64_t *no = (uint64_t *)realloc(ix->off, sizeof(uint64_t) * (size_t)nc);
+        if (no) ix->off = no;
+        uint32_t *nl = (uint32_t *)realloc(ix->caplen, sizeof(uint32_t) * (size_t)nc);
+        if (nl) ix->caplen = nl;
+        if (!no || !nl) return KMPHOST_ENOMEM;
+        ix->cap = nc;
+    }
+    ix->off[ix->n] = off; ix->caplen[ix->n] = cl; ix->n++;
+    return KMPHOST_OK;
+}
+
+static int index_file(const kmp_view *v, kmp_index *ix, char errbuf[KMP_PCAP_ERRBUF])
+{
+    memset(ix, 0, sizeof *ix);
+    kmp_walk w;
+    int rc = walk_init(&w, v->base, v->size, errbuf);
+    if (rc) return rc;
+    uint32_t cl, ln;
+    const uint8_t *data;
+    while (walk_next(&w, &cl, &ln, &data) >= 0)                       /* serial.c:115: -1 and -2 both end the loop */
+        if ((rc = index_push(ix, (uint64_t)(data - v->base), cl)) != 0) {
+            free(ix->off); free(ix->caplen); memset(ix, 0, sizeof *ix);
+            if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory");
+            return rc;
+        }
+    return KMPHOST_OK;
+}
+
 int kmp_arena_from_pcap(const char *path, int proto, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn,
                         kmp_arena *out, char errbuf[KMP_PCAP_ERRBUF])
 {
     memset(out, 0, sizeof *out);
-    uint64_t n = 0, frames = 0, bytes = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        kmp_pcap *p = kmp_pcap_open(path, errbuf);
-        if (!p) return errbuf && !strcmp(errbuf, "unknown file format") ? KMPHOST_EFORMAT : KMPHOST_EIO;
-        uint32_t cl, ln;
-        const uint8_t *data;
-        uint64_t k = 0, pos = 0;
-        while (kmp_pcap_next(p, &cl, &ln, &data) >= 0) {            /* serial.c:115 */
-            uint32_t po, pl;
-            const int ok = (proto == KMP_PROTO_TCP) ? kmp_extract_tcp(data, cl, &po, &pl)
-                                                    : kmp_extract_udp(data, cl, &po, &pl);   /* :119-122 */
-            if (pass == 0) frames++;
-            if (!ok) continue;                                      /* serial.c:138-140: skipped */
-            if (pass == 1) {
-                out->off[k] = pos;
-                out->len[k] = pl;
-                if (pl) memcpy(out->bytes + pos, data + po, pl);    /* serial.c:125-127 */
-                out->payload_bytes += pl;
-            }
-            pos += round_up(pl ? pl : 1, KMP_SLOT_ALIGN);
-            k++;
+    kmp_view v;
+    kmp_index ix;
+    int rc = view_open(path, &v, errbuf);
+    if (rc) return rc;
+    if ((rc = index_file(&v, &ix, errbuf)) != 0) { view_close(&v); return rc; }
+    const int64_t nf = (int64_t)ix.n;
+    const int nt = host_threads();
+    (void)nt;
+    /* the extraction rule for every frame (serial.c:119-122 / openmp_data.c:128-147 do this per packet too) */
+    uint32_t *po = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nf ? nf : 1));
+    uint32_t *pl = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nf ? nf : 1));
+    uint64_t *dst = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nf ? nf : 1));
+    if (!po || !pl || !dst) rc = KMPHOST_ENOMEM;
+    if (!rc) {
+#pragma omp parallel for num_threads(nt) schedule(static)
+        for (int64_t f = 0; f < nf; f++) {
+            uint32_t o = 0, l = 0;
+            const int ok = (proto == KMP_PROTO_TCP) ? kmp_extract_tcp(v.base + ix.off[f], ix.caplen[f], &o, &l)
+                                                    : kmp_extract_udp(v.base + ix.off[f], ix.caplen[f], &o, &l);
+            po[f] = o; pl[f] = ok ? l : UINT32_MAX;                 /* UINT32_MAX: skipped (serial.c:138-140) */
         }
-        kmp_pcap_close(p);
-        if (pass == 0) {
-            n = k; bytes = pos + KMP_ARENA_SLACK;
-            int rc = arena_alloc(out, bytes, n, alloc_fn, free_fn);
-            if (rc) { if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return rc; }
+        uint64_t n = 0, pos = 0, payload = 0;
+        for (int64_t f = 0; f < nf; f++) {
+            if (pl[f] == UINT32_MAX) continue;
+            dst[f] = pos;
+            pos += round_up(pl[f] ? pl[f] : 1, KMP_SLOT_ALIGN);
+            payload += pl[f];
+            n++;
+        }
+        rc = arena_alloc(out, pos + KMP_ARENA_SLACK, n, alloc_fn, free_fn, 0);
+        if (!rc) {
+            uint64_t k = 0;
+            for (int64_t f = 0; f < nf; f++) {
+                if (pl[f] == UINT32_MAX) continue;
+                out->off[k] = dst[f]; out->len[k] = pl[f]; k++;
+            }
+            /* payload copies (serial.c:125-127) + zeroed slot padding, one stream per thread */
+#pragma omp parallel for num_threads(nt) schedule(static)
+            for (int64_t f = 0; f < nf; f++) {
+                if (pl[f] == UINT32_MAX) continue;
+                const uint64_t slot = round_up(pl[f] ? pl[f] : 1, KMP_SLOT_ALIGN);
+                uint8_t *d = out->bytes + dst[f];
+                if (pl[f]) memcpy(d, v.base + ix.off[f] + po[f], pl[f]);
+                if (slot > pl[f]) memset(d + pl[f], 0, (size_t)(slot - pl[f]));
+            }
+            memset(out->bytes + pos, 0, KMP_ARENA_SLACK);
+            out->n_pkts = n;
+            out->n_frames = (uint64_t)nf;
+            out->payload_bytes = payload;
         }
     }
-    out->n_pkts = n;
-    out->n_frames = frames;
-    return KMPHOST_OK;
+    if (rc == KMPHOST_ENOMEM && errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory");
+    free(po); free(pl); free(dst);
+    free(ix.off); free(ix.caplen);
+    view_close(&v);
+    return rc;
 }
 
 /* ============================ raw frames (on-device extraction) ========================= */
@@ -408,83 +544,36 @@ int kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn fr
                          char errbuf[KMP_PCAP_ERRBUF])
 {
     memset(out, 0, sizeof *out);
-    if (errbuf) errbuf[0] = 0;
-    FILE *fp = fopen(path, "rb");
-    if (!fp) { if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: %s", path, strerror(errno)); return KMPHOST_EIO; }
-    fseek(fp, 0, SEEK_END);
-    const long sz = ftell(fp);
-    fseek(fp, 0, SEEK_SET);
-    if (sz < 24) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "truncated dump file; tried to read 24 file header bytes"); return KMPHOST_EIO; }
+    kmp_view v;
+    kmp_index ix;
+    int rc = view_open(path, &v, errbuf);
+    if (rc) return rc;
+    if ((rc = index_file(&v, &ix, errbuf)) != 0) { view_close(&v); return rc; }
     out->free_fn = alloc_fn ? free_fn : free;
-    out->nbytes = (uint64_t)sz;
-    out->bytes = (uint8_t *)(alloc_fn ? alloc_fn((size_t)sz + 64) : malloc((size_t)sz + 64));
-    if (!out->bytes) { fclose(fp); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return KMPHOST_ENOMEM; }
-    if (fread(out->bytes, 1, (size_t)sz, fp) != (size_t)sz) {
-        fclose(fp); kmp_frames_free(out);
-        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "%s: short read", path);
-        return KMPHOST_EIO;
+    out->nbytes = v.size;
+    out->bytes = (uint8_t *)(alloc_fn ? alloc_fn((size_t)v.size + 64) : malloc((size_t)v.size + 64));
+    if (!out->bytes) {
+        free(ix.off); free(ix.caplen); view_close(&v);
+        if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory");
+        return KMPHOST_ENOMEM;
     }
-    fclose(fp);
-    memset(out->bytes + sz, 0, 64);
-    uint32_t magic;
-    memcpy(&magic, out->bytes, 4);
-    int swap, ng = 0;
-    uint32_t bom = 0;
-    memcpy(&bom, out->bytes + 8, 4);
-    if (magic == 0xA1B2C3D4u || magic == 0xA1B23C4Du) swap = 0;
-    else if (bswap32(magic) == 0xA1B2C3D4u || bswap32(magic) == 0xA1B23C4Du) swap = 1;
-    else if (magic == PCAPNG_SHB && (bom == PCAPNG_BOM || bswap32(bom) == PCAPNG_BOM)) { ng = 1; swap = 0; }
-    else { kmp_frames_free(out); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "unknown file format"); return KMPHOST_EFORMAT; }
-    for (int pass = 0; pass < 2; pass++) {
-        uint64_t pos = ng ? 0 : 24, n = 0;
-        uint32_t snap = 0;
-        while (ng && pos + 12 <= (uint64_t)sz) {                               /* pcapng: walk the blocks */
-            uint32_t type, total, w[5];
-            memcpy(&type, out->bytes + pos, 4);
-            memcpy(&total, out->bytes + pos + 4, 4);
-            if (type == PCAPNG_SHB) {
-                memcpy(&bom, out->bytes + pos + 8, 4);
-                if (bom == PCAPNG_BOM) swap = 0; else if (bswap32(bom) == PCAPNG_BOM) swap = 1; else break;
-                snap = 0;
-            }
-            if (swap) { type = bswap32(type); total = bswap32(total); }
-            if (total < 12u || (total & 3u) || pos + total > (uint64_t)sz) break;
-            const uint32_t body = total - 12u;
-            const uint8_t *b = out->bytes + pos + 8;
-            uint64_t doff = 0; uint32_t cl = 0; int pkt = 0;
-            if ((type == 6u || type == 2u) && body >= 20u) {
-                memcpy(w, b, 20);
-                cl = swap ? bswap32(w[3]) : w[3];
-                if (cl > body - 20u) break;
-                doff = pos + 8 + 20; pkt = 1;
-            } else if (type == 3u && body >= 4u) {
-                memcpy(w, b, 4);
-                cl = swap ? bswap32(w[0]) : w[0];
-                if (snap && cl > snap) cl = snap;
-                if (cl > body - 4u) cl = body - 4u;
-                doff = pos + 8 + 4; pkt = 1;
-            } else if (type == 1u && body >= 8u && snap == 0) {
-                memcpy(w, b + 4, 4);
-                snap = swap ? bswap32(w[0]) : w[0];
-            }
-            if (pkt) { if (pass) { out->off[n] = doff; out->caplen[n] = cl; } n++; }
-            pos += total;
-        }
-        while (!ng && pos + 16 <= (uint64_t)sz) {
-            uint32_t cl;
-            memcpy(&cl, out->bytes + pos + 8, 4);
-            if (swap) cl = bswap32(cl);
-            if (cl > (64u << 20) || pos + 16 + cl > (uint64_t)sz) break;      /* truncated / corrupt record ends the walk (serial.c:115) */
-            if (pass) { out->off[n] = pos + 16; out->caplen[n] = cl; }
-            pos += 16 + (uint64_t)cl; n++;
-        }
-        if (!pass) {
-            out->n = n;
-            out->off = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
-            out->caplen = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
-            if (!out->off || !out->caplen) { kmp_frames_free(out); return KMPHOST_ENOMEM; }
-        }
+    /* the file as it is, copied by several threads (the destination is usually pinned memory) */
+    const int nt = host_threads();
+    (void)nt;
+    const uint64_t piece = 4u << 20;
+    const int64_t pieces = (int64_t)((v.size + piece - 1) / piece);
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int64_t i = 0; i < pieces; i++) {
+        const uint64_t o = (uint64_t)i * piece, l = (v.size - o < piece) ? v.size - o : piece;
+        memcpy(out->bytes + o, v.base + o, (size_t)l);
     }
+    memset(out->bytes + v.size, 0, 64);
+    out->off = ix.off; out->caplen = ix.caplen; out->n = ix.n;
+    if (!out->off) {                                     /* no record: keep the arrays non-NULL */
+        out->off = (uint64_t *)malloc(sizeof(uint64_t)); out->caplen = (uint32_t *)malloc(sizeof(uint32_t));
+        if (!out->off || !out->caplen) { kmp_frames_free(out); view_close(&v); return KMPHOST_ENOMEM; }
+    }
+    view_close(&v);
     return KMPHOST_OK;
 }
 
@@ -499,21 +588,27 @@ void kmp_frames_free(kmp_frames *f)
 /* ============================ streamed capture: batches =================================
  * The producer half of openmp_task.c:126-155. */
 struct kmp_batch_reader {
-    kmp_pcap      *p;
-    int            proto;
-    int            pending;          /* a record has been read but did not fit into the previous batch */
-    uint32_t       cl;
-    const uint8_t *data;
-    int            eof;
+    kmp_view  view;
+    kmp_walk  walk;
+    int       proto;
+    int       pending;          /* a payload has been found but did not fit into the previous batch */
+    uint64_t  p_src;            /* its bytes in the file, its length */
+    uint32_t  p_len;
+    int       eof;
+    uint64_t *src;              /* scratch: source offset of every payload of the batch being built */
+    uint64_t  src_cap;
 };
 
 kmp_batch_reader *kmp_batch_open(const char *path, int proto, char errbuf[KMP_PCAP_ERRBUF])
 {
-    kmp_pcap *p = kmp_pcap_open(path, errbuf);
-    if (!p) return NULL;
     kmp_batch_reader *r = (kmp_batch_reader *)calloc(1, sizeof *r);
-    if (!r) { kmp_pcap_close(p); if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
-    r->p = p; r->proto = proto;
+    if (!r) { if (errbuf) snprintf(errbuf, KMP_PCAP_ERRBUF, "out of memory"); return NULL; }
+    if (view_open(path, &r->view, errbuf) || walk_init(&r->walk, r->view.base, r->view.size, errbuf)) {
+        view_close(&r->view);
+        free(r);
+        return NULL;
+    }
+    r->proto = proto;
     return r;
 }
 
@@ -523,25 +618,41 @@ int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, 
     uint64_t n = 0, pos = 0;
     if (cap_bytes < KMP_ARENA_SLACK + KMP_SLOT_ALIGN) return KMPHOST_EINVAL;
     const uint64_t room = cap_bytes - KMP_ARENA_SLACK;
+    /* 1: walk the records and lay the batch out (sequential: headers only) */
     while (!r->eof) {
         if (!r->pending) {
-            uint32_t ln;
-            if (kmp_pcap_next(r->p, &r->cl, &ln, &r->data) < 0) { r->eof = 1; break; }   /* openmp_task.c:135 */
+            uint32_t cl, ln, po, pl;
+            const uint8_t *data;
+            if (walk_next(&r->walk, &cl, &ln, &data) < 0) { r->eof = 1; break; }          /* openmp_task.c:135 */
             if (frames) (*frames)++;
-            r->pending = 1;
+            const int ok = (r->proto == KMP_PROTO_TCP) ? kmp_extract_tcp(data, cl, &po, &pl)
+                                                       : kmp_extract_udp(data, cl, &po, &pl);   /* openmp_task.c:139-142 */
+            if (!ok) continue;                          /* invalid frames cannot match anything (openmp_task.c:150-153 stores " ") */
+            r->p_src = (uint64_t)(data - r->view.base) + po; r->p_len = pl; r->pending = 1;
         }
-        uint32_t po, pl;
-        const int ok = (r->proto == KMP_PROTO_TCP) ? kmp_extract_tcp(r->data, r->cl, &po, &pl)
-                                                   : kmp_extract_udp(r->data, r->cl, &po, &pl);   /* openmp_task.c:139-142 */
-        if (!ok) { r->pending = 0; continue; }      /* invalid frames cannot match anything (openmp_task.c:150-153 stores " ") */
-        const uint64_t slot = round_up(pl ? pl : 1, KMP_SLOT_ALIGN);
+        const uint64_t slot = round_up(r->p_len ? r->p_len : 1, KMP_SLOT_ALIGN);
         if (slot > room) return KMPHOST_EINVAL;
-        if (pos + slot > room || n == cap_pkts) break;           /* keep the record for the next batch */
-        off[n] = pos; len[n] = pl;
-        if (pl) memcpy(arena + pos, r->data + po, pl);
-        if (slot > pl) memset(arena + pos + pl, 0, (size_t)(slot - pl));
+        if (pos + slot > room || n == cap_pkts) break;                /* keep the payload for the next batch */
+        if (n == r->src_cap) {
+            const uint64_t nc = r->src_cap ? r->src_cap * 2 : 1u << 16;
+            uint64_t *ns = (uint64_t *)realloc(r->src, sizeof(uint64_t) * (size_t)nc);
+            if (!ns) return KMPHOST_ENOMEM;
+            r->src = ns; r->src_cap = nc;
+        }
+        r->src[n] = r->p_src;
+        off[n] = pos; len[n] = r->p_len;
         pos += slot; n++;
         r->pending = 0;
+    }
+    /* 2: copy the payloads, several threads (the arena is usually pinned memory) */
+    const int nt = host_threads();
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (int64_t k = 0; k < (int64_t)n; k++) {
+        const uint64_t slot = round_up(len[k] ? len[k] : 1, KMP_SLOT_ALIGN);
+        uint8_t *d = arena + off[k];
+        if (len[k]) memcpy(d, r->view.base + r->src[k], len[k]);
+        if (slot > len[k]) memset(d + len[k], 0, (size_t)(slot - len[k]));
     }
     if (n) memset(arena + pos, 0, KMP_ARENA_SLACK);
     if (used_bytes) *used_bytes = n ? pos + KMP_ARENA_SLACK : 0;
@@ -551,7 +662,8 @@ int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, 
 void kmp_batch_close(kmp_batch_reader *r)
 {
     if (!r) return;
-    kmp_pcap_close(r->p);
+    view_close(&r->view);
+    free(r->src);
     free(r);
 }
 
