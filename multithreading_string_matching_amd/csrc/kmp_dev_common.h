@@ -61,12 +61,12 @@ __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-/* Candidate test for the 16 start offsets of a lane, VALU only: min over (dword ^ first);
- * 12 v_alignbyte + 16 v_xor + 8 v_min3 and no scalar work. */
+/* Candidate test for the 16 start offsets of a lane, VALU only: min over (dword ^ first), kept per group of
+ * four offsets (g[q] covers offsets 4q..4q+3) so that the rare path only looks at the groups that hold a
+ * candidate; 12 v_alignbyte + 16 v_xor + 4 v_min + 6 v_min3 and no scalar work. */
 template <bool MASKED>
-__device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t first, uint32_t mask)
+__device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t first, uint32_t mask, uint32_t (&g)[4])
 {
-    uint32_t acc = 0xFFFFFFFFu;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t lo = w[q], hi = w[q + 1];
@@ -75,10 +75,9 @@ __device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t 
         uint32_t x2 = __builtin_amdgcn_alignbyte(hi, lo, 2) ^ first;
         uint32_t x3 = __builtin_amdgcn_alignbyte(hi, lo, 3) ^ first;
         if (MASKED) { x0 &= mask; x1 &= mask; x2 &= mask; x3 &= mask; }
-        acc = min3u(acc, x0, x1);
-        acc = min3u(acc, x2, x3);
+        g[q] = min3u(min(x0, x1), x2, x3);
     }
-    return acc;                 /* 0 iff some start offset of this lane shows the pattern's first bytes */
+    return min3u(min(g[0], g[1]), g[2], g[3]);      /* 0 iff some start offset of this lane shows the pattern's first bytes */
 }
 
 /* ballot of a lane predicate: the compare's SGPR pair itself, no VALU select */
@@ -227,7 +226,7 @@ __device__ __forceinline__ int32_t nul_limit(int32_t maxi, const uint32_t (&w)[5
  * compared dword-wise straight from registers (W = the lane's 16 bytes + the next 20 of the stream);
  * everything else runs the KMP automaton. */
 template <bool MASKED, bool EMIT>
-__device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], uint4 v, u32x4 bn, int32_t maxi, uint32_t p0, uint32_t L,
+__device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], const uint32_t (&g)[4], uint4 v, u32x4 bn, int32_t maxi, uint32_t p0, uint32_t L,
                                               const PatConst &pc, const kmp_pattern_dev &sp, uint32_t &cnt, uint64_t pkt,
                                               const Emitter &em)
 {
@@ -236,6 +235,7 @@ __device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], uint4 v, u
     if (m <= 4u) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (ballot64(g[q] == 0u) == 0ull) continue;           /* no lane has a candidate among offsets 4q..4q+3 */
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
@@ -250,6 +250,7 @@ __device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], uint4 v, u
                                     wave_shl1(v.w, sgpr(bn.w)), wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (ballot64(g[q] == 0u) == 0ull) continue;
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];

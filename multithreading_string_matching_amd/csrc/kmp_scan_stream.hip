@@ -101,7 +101,8 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
-                    const uint32_t fm = filter_min<MASKED>(w, first, mask);
+                    uint32_t g[4];
+                    const uint32_t fm = filter_min<MASKED>(w, first, mask, g);
                     const uint64_t zl = ballot64(zm != 0u);                   /* lanes holding a 0x00           */
                     const uint64_t st = ballot64(p0 == 0u);                   /* lanes where a packet starts    */
                     const uint64_t cl = ballot64(fm == 0u);                   /* lanes with a candidate         */
@@ -117,7 +118,7 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                         if (fm != 0u) maxi = -1;
                         if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
                         const uint64_t pkt = EMIT ? (k0 + (uint64_t)((cb + vo0 - p0) / stride)) : 0ull;
-                        confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, pkt, em);
+                        confirm_lanes<MASKED, EMIT>(w, g, v, bn, maxi, p0, L, pc, s_pat, cnt, pkt, em);
                     }
                     /* this lane's position inside its packet, one chunk further */
                     p0 += step_mod;
@@ -274,7 +275,8 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
-                    const uint32_t fm = filter_min<MASKED>(w, first, mask);
+                    uint32_t g[4];
+                    const uint32_t fm = filter_min<MASKED>(w, first, mask, g);
                     const uint64_t zl = ballot64(zm != 0u);
                     const uint64_t cl = ballot64(fm == 0u);
                     const bool dead_in = dead;
@@ -313,7 +315,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                             maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
                         }
                         if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
-                        confirm_lanes<MASKED, EMIT>(w, v, bn, maxi, p0, L, pc, s_pat, cnt, kl, em);
+                        confirm_lanes<MASKED, EMIT>(w, g, v, bn, maxi, p0, L, pc, s_pat, cnt, kl, em);
                         /* leave nothing of the rare path's LDS/scalar reads "possibly in flight": merged into the
                          * common path that state costs an s_waitcnt lgkmcnt(0) per chunk, which would also wait
                          * for the bitmap words just asked for */
