@@ -6,9 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import multithreading_string_matching_amd as K
-from multithreading_string_matching_amd.matcher import GpuMatcher, OPT_KERNEL
+from multithreading_string_matching_amd.matcher import GpuMatcher, OPT_KERNEL, OPT_BLOCKS_PER_CU
 
 m = GpuMatcher(0)
+BPC = [int(x) for x in os.environ.get('KMP_BPC', '0,0').split(',')]      # blocks/CU for (flat, packed); 0 = library default
 for plant in (100, 5):
     for L in (64, 128, 200, 256, 384, 512, 768, 1024, 1500):
         n = 768_000_000 // L
@@ -19,8 +20,8 @@ for plant in (100, 5):
         torch.cuda.synchronize(); m.synth_fill(d_arena, d_off, d_len, sp); m.sync()
         m.set_patterns([b"NEEDLE_16B_PATRN"]); m.attach_arena(d_arena, d_off, d_len)
         res = []
-        for kern in (0, 2):
-            m.set_option(OPT_KERNEL, kern)
+        for kern in (3, 2):
+            m.set_option(OPT_KERNEL, kern); m.set_option(OPT_BLOCKS_PER_CU, BPC[0 if kern == 3 else 1])
             for _ in range(40): m.scan_enqueue()
             m.sync()
             N = 60
