@@ -78,9 +78,11 @@ class GpuMatcher:
                                               d_len.data_ptr(), n), "kmpgpu_attach_arena")
         self._keep = (d_arena, d_off, d_len)
 
-    def load_pcap_frames(self, path: str, proto: str = "udp") -> int:
-        """Upload the raw capture and extract the payloads on the GPU (kmpgpu_load_frames).
-        Returns the number of payloads accepted."""
+    def load_pcap_frames(self, path: str, proto: str = "udp", rank: int = 0, world: int = 1) -> Tuple[int, int]:
+        """Upload the raw capture and extract the payloads on the GPU (kmpgpu_load_frames).  With world > 1
+        only this rank's share of the FRAMES is extracted (n / world each, the remainder to rank 0:
+        mpi_dumping.c:149-157).  Returns (payloads accepted, frames in the file)."""
+        from .dist import shard_range
         H = _lib.host_lib()
         fr = _lib.Frames()
         err = C.create_string_buffer(_lib.KMP_PCAP_ERRBUF)
@@ -89,10 +91,13 @@ class GpuMatcher:
             raise _lib.KmpHostError(f"error reading pcap file: {err.value.decode(errors='replace')} ({rc})")
         try:
             n = C.c_uint64()
-            gpu_check(self._g.kmpgpu_load_frames(self._ctx, fr.bytes, fr.nbytes, fr.off, fr.caplen, fr.n, 1 if proto == "tcp" else 0,
+            lo, hi = shard_range(int(fr.n), rank, world)
+            off = C.cast(C.addressof(fr.off.contents) + 8 * lo, _lib.u64p) if fr.n else fr.off
+            cl = C.cast(C.addressof(fr.caplen.contents) + 4 * lo, _lib.u32p) if fr.n else fr.caplen
+            gpu_check(self._g.kmpgpu_load_frames(self._ctx, fr.bytes, fr.nbytes, off, cl, hi - lo, 1 if proto == "tcp" else 0,
                                                  C.byref(n)), "kmpgpu_load_frames")
             self._keep = None
-            return int(n.value)
+            return int(n.value), int(fr.n)
         finally:
             H.kmp_frames_free(C.byref(fr))
 

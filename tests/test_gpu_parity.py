@@ -6,11 +6,14 @@ Run on a real MI355X:  python -m pytest tests -m gpu
 import os
 import random
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 from conftest import DATA
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -728,7 +731,7 @@ def test_device_extraction_fixtures(gm, fixture_counts, tokens, key):
     path = os.path.join(DATA, fx["pcap"])
     gm.set_option(OPT_MODE, MODE_FILTER)
     gm.set_patterns(tokens)
-    assert gm.load_pcap_frames(path, fx["mode"]) == fx["payloads"]
+    assert gm.load_pcap_frames(path, fx["mode"])[0] == fx["payloads"]
     assert gm.arena_info() == (fx["payloads"], fx["payload_bytes"])
     _same_arena(gm, K.HostArena.from_pcap(path, fx["mode"]))
     assert gm.scan()[0].tolist() == fx["counts"]
@@ -760,7 +763,7 @@ def test_device_extraction_crafted_frames(gm, kat_extract, tmp_path):
         path = tmp_path / f"crafted_{proto}.pcap"
         path.write_bytes(blob)
         host = K.HostArena.from_pcap(str(path), proto)
-        assert gm.load_pcap_frames(str(path), proto) == host.n_pkts > 10
+        assert gm.load_pcap_frames(str(path), proto)[0] == host.n_pkts > 10
         _same_arena(gm, host)
 
 
@@ -838,6 +841,38 @@ def test_border_rich_pattern_two_letter_text(gm, oracle):
         assert got.tolist() == want.tolist(), (mode, kernel)
     gm.set_option(OPT_MODE, MODE_FILTER); gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
     gm.set_stream(None)
+
+
+def _torchrun_mpi(nproc, args, port, env_extra=None):
+    env = dict(os.environ, KMPGPU_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "multithreading_string_matching_amd.mpi_dumping"] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+
+
+@pytest.mark.parametrize("key,nproc", [("big_udp.pcap:udp", 2), ("udp_1000.pcap:tcp", 3)])
+def test_mpi_dumping_program(fixture_counts, tokens, key, nproc):
+    """The multi-process program (mpi_dumping.c with GPUs for ranks): frames sharded n / P with the remainder on
+    rank 0, extraction + counting per rank on the GPU, one all-reduce, the report once.  Ranks share the one
+    GPU of the test box, so the collective runs over gloo; the program is the one the 8-GPU node runs over RCCL."""
+    fx = fixture_counts["fixtures"][key]
+    r = _torchrun_mpi(nproc, [os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt"), fx["mode"]], 29561 + nproc)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout[r.stdout.index("Printing the number"):]        # gloo announces its connections on stdout first; RCCL does not
+    assert _strip_elapsed(out) == K.format_report(tokens, fx["counts"])
+    assert r.stdout.count("Elapsed time = ") == 1 and r.stdout.count("Printing the number") == 1
+
+
+def test_mpi_dumping_program_errors(tmp_path):
+    strings = os.path.join(DATA, "strings.txt")
+    r = _torchrun_mpi(1, [os.path.join(DATA, "udp.pcap"), strings], 29571)                     # mpi_dumping.c:64-67: the protocol is mandatory
+    assert r.returncode != 0 and "USAGE: ./serial <file.pcap> <strings.txt> [tcp/udp]" in r.stdout
+    r = _torchrun_mpi(1, [os.path.join(DATA, "udp.pcap"), strings, "icmp"], 29572)
+    assert r.returncode != 0 and "USAGE ./serial <file.pcap> <strings.txt> [tcp/udp]" in r.stdout
+    r = _torchrun_mpi(2, [str(tmp_path / "missing.pcap"), strings, "udp"], 29573)              # mpi_dumping.c:110-142: message, every rank ends with 0
+    assert r.returncode == 0 and "error reading pcap file: " in r.stderr and "Elapsed" not in r.stdout
+    r = _torchrun_mpi(1, [os.path.join(DATA, "udp.pcap"), str(tmp_path / "missing.txt"), "udp"], 29574)
+    assert r.returncode != 0 and "error opening file: : " in r.stderr
 
 
 def test_cli_device_extraction(fixture_counts, tokens):
