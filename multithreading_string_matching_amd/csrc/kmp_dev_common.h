@@ -148,7 +148,7 @@ struct Emitter {
 };
 
 template <bool EMIT>
-__device__ __forceinline__ void emit_match(bool ok, uint64_t pkt, uint32_t offset, const Emitter &e)
+__device__ __forceinline__ void emit_match_as(bool ok, uint64_t pkt, uint32_t offset, uint32_t pattern, const Emitter &e)
 {
     if (!EMIT) return;
     const uint64_t b = ballot64(ok);                 /* among the lanes that are active here */
@@ -162,8 +162,14 @@ __device__ __forceinline__ void emit_match(bool ok, uint64_t pkt, uint32_t offse
     if (ok) {
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
         const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + rank;
-        if (slot < e.cap) e.out[slot] = make_uint4((uint32_t)pkt, (uint32_t)(pkt >> 32), offset, e.pattern);
+        if (slot < e.cap) e.out[slot] = make_uint4((uint32_t)pkt, (uint32_t)(pkt >> 32), offset, pattern);
     }
+}
+
+template <bool EMIT>
+__device__ __forceinline__ void emit_match(bool ok, uint64_t pkt, uint32_t offset, const Emitter &e)
+{
+    emit_match_as<EMIT>(ok, pkt, offset, e.pattern, e);
 }
 
 /* KMP automaton for the streaming kernels: the lane scans the text from its own first byte; it

@@ -45,7 +45,7 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr,
                              int accumulate = 0);
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
-                                 hipStream_t st);
+                                 const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st);
 size_t kmp_extract_ws_bytes(uint64_t n_frames);
 hipError_t kmp_launch_extract_phase1(const uint8_t *file, const uint64_t *frame_off, const uint32_t *caplen, uint64_t n, int tcp,
                                      uint8_t *ws, unsigned long long *totals, hipStream_t st);

@@ -27,12 +27,13 @@ namespace {
  *     registers, pattern records from LDS), check window-in-payload and the strlen() rule, and bump
  *     the pattern's counter in LDS.  Counters go to partials[unique pattern][block] at the end.
  * ============================================================================================== */
-template <int DEPTH, bool NT, bool CLEAN>
+template <int DEPTH, bool NT, bool CLEAN, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,
-                      unsigned long long *__restrict__ partials)
+                      unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
+                      const uint32_t *__restrict__ uid_ids)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
      * into the ds_read offset field; records, counters and one chunk window per wavefront follow dynamically */
@@ -76,6 +77,8 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
         }
         unsigned long long low = bw[0];
         uint64_t kcur = k0 - 1ull;           /* last packet that has started                                   */
+        uint64_t kbase = k0 - 1ull;          /* EMIT: the same, kept in both variants of the payload-end logic */
+        uint32_t last_start = 0u;            /* EMIT: byte position (from the stream's first byte) of that packet's start */
         int32_t  remc = 0;                   /* payload bytes of that packet left at the chunk's first byte     */
         bool     dead = false;
         uint32_t cb = 0u, j = 0u;
@@ -195,12 +198,31 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                                 diff |= (__builtin_amdgcn_alignbyte(nx, prev, sa) ^ rec[d]) & rec[5 + d];
                                                 prev = nx;
                                             }
-                                            if (diff == 0u && (int32_t)(i + rec[10]) <= rem) atomicAdd(&s_cnt[uid], 1u);
+                                            if (diff == 0u && (int32_t)(i + rec[10]) <= rem) {
+                                                atomicAdd(&s_cnt[uid], 1u);
+                                                if constexpr (EMIT) {
+                                                    /* which packet, and how far into it: from the start bitmap (the packet that
+                                                     * holds this lane started at the highest start bit at or below the lane, or
+                                                     * before the chunk) */
+                                                    const uint64_t st_le = st & ((2ull << lane) - 1ull);
+                                                    const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
+                                                    const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
+                                                    const uint32_t offs = cb + o - pstart;
+                                                    for (uint32_t t = uid_first[uid]; t < uid_first[uid + 1u]; ++t)      /* duplicates of a pattern are reported one by one */
+                                                        emit_match_as<true>(true, pkt, offs, uid_ids[t], em);
+                                                }
+                                            }
                                         }
                                         e = (ent & 0x80000000u) ? 0xFFFFu : e + 1u;
                                     }
                                 }
                             }
+                        }
+                    }
+                    if constexpr (EMIT) {
+                        if (st != 0ull) {                                            /* packets that started in this chunk */
+                            last_start = cb + (63u - (uint32_t)__builtin_clzll(st)) * KMP_LANE_BYTES;
+                            kbase += (uint64_t)__builtin_popcountll(st);
                         }
                     }
                 }
@@ -223,15 +245,17 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 
 /* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
-                                 hipStream_t st)
+                                 const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st)
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const size_t lds = ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
-#define KMP_MULTI_LAUNCH(NT_, CLEAN_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
-        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, a.partials)
-    if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true); else KMP_MULTI_LAUNCH(false, true); }
-    else             { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false); else KMP_MULTI_LAUNCH(false, false); }
+    const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
+#define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
+        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, a.partials, em, uid_first, uid_ids)
+    if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, false, true); }
+    else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true, false); else KMP_MULTI_LAUNCH(false, true, false); }
+    else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false, false); else KMP_MULTI_LAUNCH(false, false, false); }
 #undef KMP_MULTI_LAUNCH
     return hipGetLastError();
 }

@@ -68,6 +68,7 @@ struct kmpgpu_ctx {
     uint32_t              multi_words = 0, n_multi_unique = 0, n_multi = 0;
     uint32_t             *d_multi_ids = nullptr;     /* [n_multi] pattern indices counted by the fused pass   */
     uint32_t             *d_multi_rows = nullptr;    /* [n_multi] their unique-pattern row                     */
+    uint32_t             *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
     uint32_t             *d_rest_ids = nullptr;      /* [rest_long + rest_short] everything else, long first  */
     uint32_t              rest_long = 0, rest_short = 0;
 
@@ -282,7 +283,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     }
     /* packed arenas: byte-balanced wavefront ranges (plan) + packet-start bitmap, used by the packed
      * streaming kernel (mixed lengths) and by the fused multi-pattern pass */
-    const bool fused = !emit && use_fused(c);
+    const bool fused = use_fused(c);
     bool packed = !flat && use_packed(c);
     if (packed || fused) {
         const uint64_t span = c->span_end - c->uni_off0;
@@ -323,7 +324,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         f.partials = c->d_partials;
         hipEvent_t e0, e1;
         HIP_TRY(record(e0, e1));
-        HIP_TRY(kmp_launch_scan_multi(f, c->d_multi_tables, c->multi_words, c->n_multi_unique, c->stream));
+        HIP_TRY(kmp_launch_scan_multi(f, c->d_multi_tables, c->multi_words, c->n_multi_unique, c->d_uid_first, c->d_uid_ids, c->stream));
         if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
         HIP_TRY(kmp_launch_reduce(c->d_partials, bx, c->d_multi_ids, c->n_multi, d_out, c->stream, c->d_multi_rows, c->accumulate));
         ++nl;
@@ -414,6 +415,8 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_multi_tables) (void)hipFree(c->d_multi_tables);
     if (c->d_multi_ids) (void)hipFree(c->d_multi_ids);
     if (c->d_multi_rows) (void)hipFree(c->d_multi_rows);
+    if (c->d_uid_first) (void)hipFree(c->d_uid_first);
+    if (c->d_uid_ids) (void)hipFree(c->d_uid_ids);
     if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
@@ -518,7 +521,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     }
 
     /* ---- tables of the fused multi-pattern pass (layout: kmp_device.h) ------------------------- */
-    for (uint32_t **p : {&c->d_multi_tables, &c->d_multi_ids, &c->d_multi_rows, &c->d_rest_ids})
+    for (uint32_t **p : {&c->d_multi_tables, &c->d_multi_ids, &c->d_multi_rows, &c->d_rest_ids, &c->d_uid_first, &c->d_uid_ids})
         if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
     c->n_multi_unique = c->n_multi = c->multi_words = c->rest_long = c->rest_short = 0;
     std::vector<std::string> uniq;
@@ -577,6 +580,16 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         HIP_TRY(hipMemcpy(c->d_multi_tables, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_multi_ids, multi_ids.data(), multi_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_multi_rows, multi_rows.data(), multi_rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) */
+        std::vector<uint32_t> uid_first(U + 1, 0u), uid_ids(multi_ids.size());
+        for (uint32_t r : multi_rows) uid_first[r + 1]++;
+        for (uint32_t u = 0; u < U; u++) uid_first[u + 1] += uid_first[u];
+        { std::vector<uint32_t> fill(uid_first.begin(), uid_first.end() - 1);
+          for (size_t i = 0; i < multi_ids.size(); i++) uid_ids[fill[multi_rows[i]]++] = multi_ids[i]; }
+        HIP_TRY(hipMalloc(&c->d_uid_first, uid_first.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_uid_ids, uid_ids.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->d_uid_first, uid_first.data(), uid_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_uid_ids, uid_ids.data(), uid_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!rest.empty()) HIP_TRY(hipMemcpy(c->d_rest_ids, rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->multi_words = (uint32_t)tab.size(); c->n_multi_unique = U; c->n_multi = (uint32_t)multi_ids.size();
         c->rest_long = (uint32_t)rest_l.size(); c->rest_short = (uint32_t)rest_s.size();

@@ -355,7 +355,7 @@ def _expected_matches(payloads, patterns):
 @pytest.mark.parametrize("uniform", [False, True])
 def test_scan_offsets(gm, oracle, uniform):
     rng = random.Random(23 + uniform)
-    pats = [b"ab", b"abc", b"abcab", b"b", b"abcabcabcabcabcab", b"c" * 25]
+    pats = [b"ab", b"abc", b"abcab", b"b", b"abcabcabcabcabcab", b"c" * 25, b"abc", b"ca", b"ab"]     # duplicates are reported per index
     payloads = []
     for k in range(400):
         L = 1500 if uniform else rng.randrange(0, 3000)
@@ -373,16 +373,16 @@ def test_scan_offsets(gm, oracle, uniform):
     gm.set_option(OPT_MODE, MODE_FILTER)
     gm.set_patterns(pats)
     gm.load_arena(arena)
-    for kernel in (KERNEL_AUTO, KERNEL_PACKED):
-        gm.set_option(OPT_KERNEL, kernel)
+    for kernel, fused in ((KERNEL_AUTO, 0), (KERNEL_PACKED, 0), (KERNEL_FLAT, 0), (KERNEL_AUTO, 1), (KERNEL_PACKED, 1)):
+        gm.set_option(OPT_KERNEL, kernel); gm.set_option(OPT_FUSED, fused)
         got, found, counts = gm.scan_offsets(len(want) + 10)
-        assert found == len(want) and counts.tolist() == counts_want.tolist()
-        assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in got) == want
-    # a buffer that is too small: the total is still reported, the buffer holds valid matches
-    got, found, counts = gm.scan_offsets(100)
-    assert found == len(want) and len(got) == 100
-    assert set((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in got) <= set(want)
-    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+        assert found == len(want) and counts.tolist() == counts_want.tolist(), (kernel, fused)
+        assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in got) == want, (kernel, fused)
+        # a buffer that is too small: the total is still reported, the buffer holds valid matches
+        got, found, counts = gm.scan_offsets(100)
+        assert found == len(want) and len(got) == 100
+        assert set((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in got) <= set(want)
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
 
 
 def test_scan_offsets_fixture(gm, tokens, fixture_counts):
@@ -483,9 +483,13 @@ def test_dirty_slot_padding(gm, oracle, uniform):
             gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
             assert gm.scan()[0].tolist() == want.tolist(), ("borrowed", kernel)
         assert np.array_equal(d_arena.cpu().numpy(), arena)
-        gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 0)
-        recs, found, cnts = gm.scan_offsets(int(want.sum()) + 10)
-        assert found == int(want.sum()) and cnts.tolist() == want.tolist()
+        for fused in (0, 1):                                  # borrowed + dirty: the emitting kernels read the index too
+            gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, fused)
+            recs, found, cnts = gm.scan_offsets(int(want.sum()) + 10)
+            assert found == int(want.sum()) == len(recs) and cnts.tolist() == want.tolist()
+            for r in recs[:: max(1, len(recs) // 300)]:
+                o = int(off[int(r["packet"])]) + int(r["offset"]); p = pats[int(r["pattern"])]
+                assert arena[o:o + len(p)].tobytes() == p and int(r["offset"]) + len(p) <= lens[int(r["packet"])]
     finally:
         gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
 
