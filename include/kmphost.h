@@ -115,7 +115,11 @@ typedef struct kmp_frames {
     uint32_t *caplen;         /* caplen[f]: captured bytes of frame f                */
     uint64_t  n;
     kmp_free_fn free_fn;
+    uint64_t  map_len;        /* != 0: bytes is the file mapping itself (no copy was made), released by munmap */
 } kmp_frames;
+/* alloc_fn == NULL: no copy at all -- bytes is the read-only mapping of the file (a host-to-device copy
+ * straight from it runs at PCIe speed on the MI355X hosts, profiles/r01_h2d_probe.txt); with an allocator
+ * the file is copied into its memory by several threads. */
 int  kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn free_fn, kmp_frames *out,
                           char errbuf[KMP_PCAP_ERRBUF]);
 void kmp_frames_free(kmp_frames *f);

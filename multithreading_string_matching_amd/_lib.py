@@ -69,7 +69,8 @@ class Arena(C.Structure):
 
 class Frames(C.Structure):
     """kmp_frames (include/kmphost.h)."""
-    _fields_ = [("bytes", u8p), ("nbytes", C.c_uint64), ("off", u64p), ("caplen", u32p), ("n", C.c_uint64), ("free_fn", C.c_void_p)]
+    _fields_ = [("bytes", u8p), ("nbytes", C.c_uint64), ("off", u64p), ("caplen", u32p), ("n", C.c_uint64), ("free_fn", C.c_void_p),
+                ("map_len", C.c_uint64)]
 
 
 class Timing(C.Structure):

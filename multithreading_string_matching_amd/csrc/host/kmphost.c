@@ -31,6 +31,22 @@ typedef struct kmp_view {
     int            mapped;       /* 1: munmap, 0: free (fallback for what cannot be mapped, e.g. a pipe) */
 } kmp_view;
 
+static int host_threads(void);
+
+/* A large mapping is walked record by record right after it is made; taking its ~250 000 page faults per GB on
+ * one thread costs more than the walk itself, so several threads touch the pages first. */
+static void view_prefault(const kmp_view *v)
+{
+    if (v->size < (64u << 20)) return;
+    const int nt = host_threads();
+    (void)nt;
+    const int64_t pages = (int64_t)((v->size + 4095u) >> 12);
+    uint64_t sink = 0;
+#pragma omp parallel for num_threads(nt) schedule(static) reduction(+ : sink)
+    for (int64_t p = 0; p < pages; p++) sink += v->base[(uint64_t)p << 12];
+    __asm__ volatile("" :: "r"(sink));
+}
+
 static int view_open(const char *path, kmp_view *v, char errbuf[KMP_PCAP_ERRBUF])
 {
     memset(v, 0, sizeof *v);
@@ -49,6 +65,7 @@ static int view_open(const char *path, kmp_view *v, char errbuf[KMP_PCAP_ERRBUF]
                 (void)madvise(m, (size_t)v->size, MADV_WILLNEED);
                 v->base = (const uint8_t *)m; v->mapped = 1;
                 close(fd);
+                view_prefault(v);
                 return KMPHOST_OK;
             }
         } else { close(fd); return KMPHOST_OK; }
@@ -549,6 +566,15 @@ int kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn fr
     int rc = view_open(path, &v, errbuf);
     if (rc) return rc;
     if ((rc = index_file(&v, &ix, errbuf)) != 0) { view_close(&v); return rc; }
+    if (!alloc_fn && v.mapped) {                        /* hand the mapping itself out */
+        out->bytes = (uint8_t *)v.base; out->nbytes = v.size; out->map_len = v.size; out->free_fn = NULL;
+        out->off = ix.off; out->caplen = ix.caplen; out->n = ix.n;
+        if (!out->off) {
+            out->off = (uint64_t *)malloc(sizeof(uint64_t)); out->caplen = (uint32_t *)malloc(sizeof(uint32_t));
+            if (!out->off || !out->caplen) { kmp_frames_free(out); return KMPHOST_ENOMEM; }
+        }
+        return KMPHOST_OK;
+    }
     out->free_fn = alloc_fn ? free_fn : free;
     out->nbytes = v.size;
     out->bytes = (uint8_t *)(alloc_fn ? alloc_fn((size_t)v.size + 64) : malloc((size_t)v.size + 64));
@@ -580,7 +606,8 @@ int kmp_frames_from_pcap(const char *path, kmp_alloc_fn alloc_fn, kmp_free_fn fr
 void kmp_frames_free(kmp_frames *f)
 {
     if (!f) return;
-    if (f->bytes && f->free_fn) f->free_fn(f->bytes);
+    if (f->bytes && f->map_len) munmap(f->bytes, (size_t)f->map_len);
+    else if (f->bytes && f->free_fn) f->free_fn(f->bytes);
     free(f->off); free(f->caplen);
     memset(f, 0, sizeof *f);
 }

@@ -27,10 +27,10 @@ runs = [("serial (host extraction)", ["serial", pcap, strings], {}),
 for rep in range(2):                        # second round: file in the page cache for sure
     for name, argv, env in runs:
         t = time.time()
-        r = subprocess.run([os.path.join(_lib.BINDIR, argv[0])] + argv[1:], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        r = subprocess.run([os.path.join(_lib.BINDIR, argv[0])] + argv[1:], capture_output=True, text=True, env=dict(os.environ, KMPGPU_STATS="1", **env), timeout=600)
         wall = time.time() - t
         assert r.returncode == 0, r.stderr
         assert f"NEEDLE_16B_PATRN: {planted} times!" in r.stdout, r.stdout
         el = [l for l in r.stdout.splitlines() if l.startswith("Elapsed")][0]
-        print(f"[{rep}] {name:34s}: wall {wall:6.2f} s ({n*L/wall/1e9:5.2f} GB/s of payload)  {el}  | " + " | ".join(l for l in r.stderr.splitlines() if "kernel" in l or "streamed" in l), flush=True)
+        print(f"[{rep}] {name:34s}: wall {wall:6.2f} s ({n*L/wall/1e9:5.2f} GB/s of payload)  {el}  | " + " | ".join(l for l in r.stderr.splitlines() if "kernel" in l or "streamed" in l or "phases" in l), flush=True)
 os.remove(pcap)
