@@ -114,6 +114,60 @@ __global__ void __launch_bounds__(256) read_pktil(const u32x4 *__restrict__ src,
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// every wavefront reads contiguous ranges, but takes them from a global counter: ranges = PARTS x wavefronts
+// (the first one statically), so a wavefront that is slowed down ends up with fewer ranges
+template <int INFL, bool NT, int GROUPS>
+__global__ void __launch_bounds__(256) read_steal(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out, uint32_t *ticket, uint32_t parts)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nw = gridDim.x * 4u, gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t chunks = n16 / 64u;
+    const uint32_t nr = nw * parts;
+    const uint64_t per = (chunks + nr - 1) / nr;
+    u32x4 acc = {0, 0, 0, 0};
+    const uint32_t groups = GROUPS, g = gw % groups, per_group = nr / groups;      // nw and nr are multiples of GROUPS
+    uint32_t k = gw / groups;                       // index inside the group: first range statically
+    while (k < per_group) {
+        const uint32_t r = k * groups + g;
+        const uint64_t c0 = (uint64_t)r * per, c1 = std::min(chunks, c0 + per);
+        uint64_t c = c0;
+        for (; c + INFL <= c1; c += INFL) {
+            u32x4 v[INFL];
+#pragma unroll
+            for (int i = 0; i < INFL; ++i) v[i] = ld16<NT>(src + (c + i) * 64u + lane);
+#pragma unroll
+            for (int i = 0; i < INFL; ++i) acc ^= v[i];
+        }
+        for (; c < c1; ++c) acc ^= ld16<NT>(src + c * 64u + lane);
+        uint32_t nx = 0;
+        if (lane == 0) nx = atomicAdd(ticket + g * 32u, 1u);      // one counter per group, 128 bytes apart
+        k = nw / groups + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+// static ranges, every wavefront records when it finished (s_memtime, 100 MHz): how ragged is the end of a launch?
+template <int INFL, bool NT>
+__global__ void __launch_bounds__(256) read_range_t(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out, unsigned long long *tend)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nw = (uint64_t)gridDim.x * 4u, gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t chunks = n16 / 64u, per = (chunks + nw - 1) / nw;
+    const uint64_t c0 = gw * per, c1 = std::min(chunks, c0 + per);
+    u32x4 acc = {0, 0, 0, 0};
+    uint64_t c = c0;
+    for (; c + INFL <= c1; c += INFL) {
+        u32x4 v[INFL];
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) v[i] = ld16<NT>(src + (c + i) * 64u + lane);
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) acc ^= v[i];
+    }
+    for (; c < c1; ++c) acc ^= ld16<NT>(src + c * 64u + lane);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+    if (lane == 0) tend[gw] = __builtin_amdgcn_s_memrealtime();
+}
+
 template <typename F> double sustained_us(F launch)
 {
     const int warm = 60, n = 100;
@@ -145,7 +199,24 @@ int main()
 #define RUN(name, kern, bpc) do { const int b_ = cus * (bpc); \
         double us = sustained_us([&] { hipLaunchKernelGGL(kern, dim3(b_), dim3(256), 0, 0, s, n16, out); }); \
         printf("%-44s blocks/CU=%d  %7.1f us  %6.0f GB/s\n", name, bpc, us, bytes / us / 1e3); fflush(stdout); } while (0)
-    for (int bpc : {2, 3, 4, 8}) {
+    {   // how ragged is the end of a launch with static ranges?
+        const int b_ = cus * 4; unsigned long long *tend; CK(hipMalloc(&tend, sizeof(unsigned long long) * b_ * 4));
+        for (int i = 0; i < 80; ++i) hipLaunchKernelGGL((read_range_t<4, true>), dim3(b_), dim3(256), 0, 0, s, n16, out, tend);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(b_ * 4);
+        CK(hipMemcpy(h.data(), tend, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        const double us = 1.0 / 100.0;     // 100 MHz
+        printf("static ranges, finish time of the %zu wavefronts relative to the last one: p1 %.1f us, p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f\n", h.size(),
+               (h.back() - h[h.size() / 100]) * us, (h.back() - h[h.size() / 10]) * us, (h.back() - h[h.size() / 2]) * us,
+               (h.back() - h[h.size() * 9 / 10]) * us, (h.back() - h[h.size() * 99 / 100]) * us);
+        uint32_t *ticket; CK(hipMalloc(&ticket, 4096 * 128));
+#define STEAL(G, parts) do { double us2 = sustained_us([&] { hipMemsetAsync(ticket, 0, 4096 * 128, 0); \
+            hipLaunchKernelGGL((read_steal<4, true, G>), dim3(b_), dim3(256), 0, 0, s, n16, out, ticket, (uint32_t)(parts)); }); \
+        printf("ranges from %4d counters, %2d per wavefront   blocks/CU=4  %7.1f us  %6.0f GB/s\n", G, parts, us2, bytes / us2 / 1e3); fflush(stdout); } while (0)
+        for (int parts : {2, 3, 4, 8}) { STEAL(64, parts); STEAL(256, parts); STEAL(1024, parts); }
+    }
+    for (int bpc : {4}) {
         RUN("range/wave  4 in flight nt", (read_range<4, true>), bpc);
         RUN("range/wave  8 in flight nt", (read_range<8, true>), bpc);
         RUN("range/wave  4 in flight   ", (read_range<4, false>), bpc);
