@@ -114,6 +114,49 @@ __global__ void __launch_bounds__(256) read_pktil(const u32x4 *__restrict__ src,
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// tile-interleaved: tile t (TILE consecutive 1 KiB chunks, all in flight at once) goes to wavefront t % nwaves
+template <int TILE, bool NT>
+__global__ void __launch_bounds__(256) read_tiles(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nw = (uint64_t)gridDim.x * 4u, gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t chunks = n16 / 64u, tiles = chunks / TILE;
+    u32x4 acc = {0, 0, 0, 0};
+    for (uint64_t t = gw; t < tiles; t += nw) {
+        u32x4 v[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) v[i] = ld16<NT>(src + (t * TILE + i) * 64u + lane);
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) acc ^= v[i];
+    }
+    if (gw == 0) for (uint64_t c = tiles * TILE; c < chunks; ++c) acc ^= ld16<NT>(src + c * 64u + lane);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+// the access pattern a tile-interleaved scan kernel would have: per 2 KiB tile two chunk loads + the first
+// 128 bytes of the next tile (lanes 0..7), two tiles in flight per wavefront
+template <bool NT>
+__global__ void __launch_bounds__(256) read_tiles_halo(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nw = (uint64_t)gridDim.x * 4u, gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t tiles = n16 / 128u;
+    u32x4 acc = {0, 0, 0, 0};
+    const u32x4 z = {0, 0, 0, 0};
+    uint64_t t = gw;
+    if (t >= tiles) return;
+    u32x4 a0 = ld16<NT>(src + t * 128u + lane), a1 = ld16<NT>(src + t * 128u + 64u + lane);
+    u32x4 ah = (lane < 8u && t + 1 < tiles) ? ld16<NT>(src + (t + 1) * 128u + lane) : z;
+    for (t += nw; t < tiles; t += nw) {
+        const u32x4 b0 = ld16<NT>(src + t * 128u + lane), b1 = ld16<NT>(src + t * 128u + 64u + lane);
+        const u32x4 bh = (lane < 8u && t + 1 < tiles) ? ld16<NT>(src + (t + 1) * 128u + lane) : z;
+        acc ^= a0; acc ^= a1; acc ^= ah;
+        a0 = b0; a1 = b1; ah = bh;
+    }
+    acc ^= a0; acc ^= a1; acc ^= ah;
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 // every wavefront reads contiguous ranges, but takes them from a global counter: ranges = PARTS x wavefronts
 // (the first one statically), so a wavefront that is slowed down ends up with fewer ranges
 template <int INFL, bool NT, int GROUPS>
@@ -216,17 +259,15 @@ int main()
         printf("ranges from %4d counters, %2d per wavefront   blocks/CU=4  %7.1f us  %6.0f GB/s\n", G, parts, us2, bytes / us2 / 1e3); fflush(stdout); } while (0)
         for (int parts : {2, 3, 4, 8}) { STEAL(64, parts); STEAL(256, parts); STEAL(1024, parts); }
     }
-    for (int bpc : {4}) {
-        RUN("range/wave  4 in flight nt", (read_range<4, true>), bpc);
-        RUN("range/wave  8 in flight nt", (read_range<8, true>), bpc);
-        RUN("range/wave  4 in flight   ", (read_range<4, false>), bpc);
-        RUN("grid-stride 4 in flight nt", (read_stride<4, true>), bpc);
-        RUN("grid-stride 8 in flight nt", (read_stride<8, true>), bpc);
-        RUN("grid-stride 4 in flight   ", (read_stride<4, false>), bpc);
-        RUN("range/block 4 in flight nt", (read_block<4, true>), bpc);
-        RUN("range/block 8 in flight nt", (read_block<8, true>), bpc);
-        RUN("packet-interleave/block 4 in flight nt", (read_pktil<4, true>), bpc);
-        RUN("packet-interleave/block 3 in flight nt", (read_pktil<3, true>), bpc);
+    // tile-interleaved patterns against contiguous ranges, over the number of resident blocks
+    for (int blocks : {cus * 2, cus * 5 / 2, cus * 3, cus * 7 / 2, cus * 4, cus * 5, cus * 6}) {
+#define RUNB(name, kern) do { double us = sustained_us([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, s, n16, out); }); \
+        printf("%-42s blocks=%4d  %7.1f us  %6.0f GB/s\n", name, blocks, us, bytes / us / 1e3); fflush(stdout); } while (0)
+        RUNB("range/wave 4 in flight nt", (read_range<4, true>));
+        RUNB("grid-stride 1 KiB x4 in flight nt", (read_stride<4, true>));
+        RUNB("tiles of 2 KiB nt", (read_tiles<2, true>));
+        RUNB("tiles of 4 KiB nt", (read_tiles<4, true>));
+        RUNB("tiles of 2 KiB + 128 B halo, 2 in flight", (read_tiles_halo<true>));
     }
     return 0;
 }
