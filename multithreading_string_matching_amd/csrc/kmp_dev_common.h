@@ -36,7 +36,14 @@ __device__ __forceinline__ bool is_cand(uint32_t d, uint32_t first, uint32_t mas
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 
-/* Wait until at most N ring loads are outstanding; a and b are the registers about to be read. */
+/* Wait until at most N ring loads are outstanding; a and b are the registers about to be read.
+ *
+ * Rule for every ring in these kernels: a slot is named by a COMPILE-TIME index (the loops over the slots are
+ * fully unrolled).  The loads are issued from inline asm, so the compiler does not know that a slot's value
+ * arrives late; it only sees that this wait "rewrites" the slot.  Reached through a run-time index (a loop
+ * that was not unrolled), a slot would be copied into a temporary BEFORE the wait -- i.e. before the data has
+ * landed (seen once, with a ring period of 12 steps: counts went wrong on the GPU, not in any compile step).
+ * Keep ring periods short enough to unroll and check the ISA for one s_waitcnt per slot after changing a ring. */
 template <int N>
 __device__ __forceinline__ void ring_wait(u32x4 &a, u32x4 &b)
 {
