@@ -1,0 +1,87 @@
+"""What the compiler made of the streaming kernels (no GPU needed: hipcc cross-compiles gfx950).
+
+The register rings of kmp_scan_stream.hip / kmp_scan_multi.hip are driven by hand-counted s_waitcnt vmcnt(N)
+from inline asm, and their slots must be reached through compile-time indices only (kmp_dev_common.h,
+ring_wait).  These checks fail when a change breaks that silently: a ring loop that is no longer unrolled, a
+spill, a kernel that lost its occupancy."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "multithreading_string_matching_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _isa(src, tmp):
+    out = os.path.join(tmp, os.path.basename(src) + ".s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}", "-S", "--cuda-device-only",
+                        "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = open(out).read()
+    kernels = {}
+    for m in re.finditer(r"^(_Z\w+):\s*;\s*@\1\n(.*?)^\s*s_endpgm\b(.*?)^; NumVgprs: (\d+).*?^; ScratchSize: (\d+).*?^; Occupancy: (\d+)", text, re.S | re.M):
+        kernels[m.group(1)] = {"body": m.group(2), "vgprs": int(m.group(4)), "scratch": int(m.group(5)), "occupancy": int(m.group(6))}
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def stream(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    return _isa("kmp_scan_stream.hip", str(tmp_path_factory.mktemp("isa")))
+
+
+@pytest.fixture(scope="module")
+def multi(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    return _isa("kmp_scan_multi.hip", str(tmp_path_factory.mktemp("isa")))
+
+
+def _ring_waits(body, n):
+    """hand-written waits only: they sit between ;;#ASMSTART / ;;#ASMEND"""
+    return len(re.findall(r";;#ASMSTART\s*\n\s*s_waitcnt vmcnt\(%d\)\s*\n\s*;;#ASMEND" % n, body))
+
+
+def _issues(body):
+    return len(re.findall(r";;#ASMSTART\s*\n\s*s_nop 4\s*\n\s*buffer_load_dwordx4 ", body))
+
+
+def test_no_spills_no_dynamic_register_indexing(stream, multi):
+    assert len(stream) >= 30 and len(multi) >= 6
+    for name, k in list(stream.items()) + list(multi.items()):
+        assert k["scratch"] == 0, name
+        assert "movrel" not in k["body"], name                     # a ring slot reached through a run-time index
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4, 5, 6, 8])
+def test_flat_kernel_ring_is_unrolled(stream, depth):
+    ks = {n: k for n, k in stream.items() if "kmp_scan_flat_kernelILi%dE" % depth in n and "ELb0EEEv" in n}
+    assert ks, list(stream)[:5]
+    for name, k in ks.items():
+        drain = (depth + 1) // 2 if depth == 2 else 0               # the final drain waits for vmcnt(0) as well
+        assert _ring_waits(k["body"], depth - 2) == depth + drain, name     # one wait per slot of the steady-state loop
+        assert _issues(k["body"]) == 2 * depth, name                # prologue + one re-issue per slot
+        # the default (4 chunks in flight, pattern of 4+ bytes): <= 64 VGPRs, eight wavefronts per SIMD; deeper rings and the
+        # masked (< 4 bytes) variants carry more state; 4 blocks/CU need 4 wavefronts per SIMD
+        assert k["occupancy"] >= (8 if depth == 4 and "ILi4ELb0E" in name else 5), (name, k["vgprs"])
+
+
+@pytest.mark.parametrize("depth", [3, 4, 6])
+def test_packed_kernel_ring_is_unrolled(stream, depth):
+    ks = {n: k for n, k in stream.items() if "kmp_scan_packed_kernelILi%dE" % depth in n and "ELb0EEEv" in n}
+    assert ks
+    for name, k in ks.items():
+        assert _ring_waits(k["body"], depth - 2) == depth, name
+        assert _issues(k["body"]) == 2 * depth, name
+        assert k["occupancy"] >= (8 if depth == 3 and "ILi3ELb0E" in name else 5), (name, k["vgprs"])       # 3 in flight is the default here
+
+
+def test_fused_kernel_ring_is_unrolled(multi):
+    for name, k in multi.items():
+        assert _ring_waits(k["body"], 2) == 4, name
+        assert _issues(k["body"]) == 8, name
+        assert k["occupancy"] >= 7, (name, k["vgprs"])              # 7 blocks of LDS fit a CU anyway
