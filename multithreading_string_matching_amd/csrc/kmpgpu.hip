@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kmpgpu.h"
@@ -64,11 +65,17 @@ struct kmpgpu_ctx {
     uint32_t             *d_ids = nullptr;          /* [n_pat]: long patterns (m >= 4) first, then short */
     uint32_t              n_long = 0, n_short = 0;
     /* fused multi-pattern pass: unique patterns of 2..20 bytes share one arena read */
-    uint32_t             *d_multi_tables = nullptr;  /* layout: kmp_device.h KMP_MULTI_* */
-    uint32_t              multi_words = 0, n_multi_unique = 0, n_multi = 0;
-    uint32_t             *d_multi_ids = nullptr;     /* [n_multi] pattern indices counted by the fused pass   */
-    uint32_t             *d_multi_rows = nullptr;    /* [n_multi] their unique-pattern row                     */
-    uint32_t             *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
+    /* fused multi-pattern pass: the eligible patterns in groups of at most KMP_MULTI_MAX_UNIQUE distinct ones, one read
+     * of the arena per group */
+    struct FusedGroup {
+        uint32_t *d_tables = nullptr;        /* layout: kmp_device.h KMP_MULTI_*                        */
+        uint32_t *d_ids = nullptr;           /* [n_ids] pattern indices counted by this group            */
+        uint32_t *d_rows = nullptr;          /* [n_ids] their unique-pattern row                         */
+        uint32_t *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
+        uint32_t  words = 0, n_unique = 0, n_ids = 0;
+    };
+    std::vector<FusedGroup> fused_groups;
+    uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
     uint32_t             *d_rest_ids = nullptr;      /* [rest_long + rest_short] everything else, long first  */
     uint32_t              rest_long = 0, rest_short = 0;
 
@@ -123,7 +130,7 @@ bool use_flat(const kmpgpu_ctx *c)
  * beats one streaming pass per pattern -- profiles/r01_multipattern.txt). */
 bool use_fused(const kmpgpu_ctx *c)
 {
-    if (!c->packed || !c->d_bitmap || c->mode != 0 || c->kernel_sel == 1 || !c->d_multi_tables) return false;
+    if (!c->packed || !c->d_bitmap || c->mode != 0 || c->kernel_sel == 1 || c->fused_groups.empty()) return false;
     if (c->fused == 1) return c->n_multi_unique >= 2;
     return c->fused == 2 && c->n_multi_unique >= 3;
 }
@@ -152,6 +159,15 @@ uint32_t grid_blocks(const kmpgpu_ctx *c)
     uint64_t cap = (uint64_t)c->cu_count * (uint64_t)bpc;
     uint64_t b = std::min(need, cap);
     return (uint32_t)std::max<uint64_t>(b, 1);
+}
+
+void free_fused_groups(kmpgpu_ctx *c)
+{
+    for (kmpgpu_ctx::FusedGroup &g : c->fused_groups)
+        for (uint32_t *p : {g.d_tables, g.d_ids, g.d_rows, g.d_uid_first, g.d_uid_ids})
+            if (p) (void)hipFree(p);
+    c->fused_groups.clear();
+    c->n_multi_unique = 0;
 }
 
 int ensure_partials(kmpgpu_ctx *c, size_t elems)
@@ -318,17 +334,21 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     uint32_t n_long = c->n_long, n_short = c->n_short;
     size_t part_base = 0;                         /* partial rows already used */
     if (do_fused) {
-        /* one read of the arena for every unique pattern of 2..20 bytes */
-        kmp_scan_args f = a;
-        f.arena = c->d_arena;
-        f.partials = c->d_partials;
-        hipEvent_t e0, e1;
-        HIP_TRY(record(e0, e1));
-        HIP_TRY(kmp_launch_scan_multi(f, c->d_multi_tables, c->multi_words, c->n_multi_unique, c->d_uid_first, c->d_uid_ids, c->stream));
-        if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-        HIP_TRY(kmp_launch_reduce(c->d_partials, bx, c->d_multi_ids, c->n_multi, d_out, c->stream, c->d_multi_rows, c->accumulate));
-        ++nl;
-        part_base = c->n_multi_unique;
+        /* one read of the arena for every group of (at most 256) unique patterns of 2..20 bytes */
+        uint32_t max_u = 0;
+        for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) {
+            kmp_scan_args f = a;
+            f.arena = c->d_arena;
+            f.partials = c->d_partials;
+            hipEvent_t e0, e1;
+            HIP_TRY(record(e0, e1));
+            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.d_uid_first, g.d_uid_ids, c->stream));
+            if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
+            HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate));
+            ++nl;
+            max_u = std::max(max_u, g.n_unique);
+        }
+        part_base = max_u;
         ids = c->d_rest_ids; n_long = c->rest_long; n_short = c->rest_short;
     }
 
@@ -412,11 +432,7 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_plan) (void)hipFree(c->d_plan);
-    if (c->d_multi_tables) (void)hipFree(c->d_multi_tables);
-    if (c->d_multi_ids) (void)hipFree(c->d_multi_ids);
-    if (c->d_multi_rows) (void)hipFree(c->d_multi_rows);
-    if (c->d_uid_first) (void)hipFree(c->d_uid_first);
-    if (c->d_uid_ids) (void)hipFree(c->d_uid_ids);
+    free_fused_groups(c);
     if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
@@ -521,31 +537,37 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     }
 
     /* ---- tables of the fused multi-pattern pass (layout: kmp_device.h) ------------------------- */
-    for (uint32_t **p : {&c->d_multi_tables, &c->d_multi_ids, &c->d_multi_rows, &c->d_rest_ids, &c->d_uid_first, &c->d_uid_ids})
-        if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
-    c->n_multi_unique = c->n_multi = c->multi_words = c->rest_long = c->rest_short = 0;
-    std::vector<std::string> uniq;
-    std::vector<uint32_t> multi_ids, multi_rows, rest_l, rest_s;
+    free_fused_groups(c);
+    if (c->d_rest_ids) { HIP_TRY(hipFree(c->d_rest_ids)); c->d_rest_ids = nullptr; }
+    c->rest_long = c->rest_short = 0;
+    struct HostGroup { std::vector<std::string> uniq; std::vector<uint32_t> ids, rows; };
+    std::vector<HostGroup> hg;
+    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> where;        /* pattern -> (group, row) */
+    std::vector<uint32_t> rest_l, rest_s;
     for (uint32_t i = 0; i < n_pat; i++) {
         const uint32_t m = pat_len[i];
+        if (m < KMP_MULTI_MIN_LEN || m > KMP_MULTI_MAX_LEN) { (m >= 4 ? rest_l : rest_s).push_back(i); continue; }
         const std::string key((const char *)pat[i], m);
-        uint32_t uid = UINT32_MAX;
-        if (m >= KMP_MULTI_MIN_LEN && m <= KMP_MULTI_MAX_LEN) {
-            auto it = std::find(uniq.begin(), uniq.end(), key);
-            if (it != uniq.end()) uid = (uint32_t)(it - uniq.begin());
-            else if (uniq.size() < KMP_MULTI_MAX_UNIQUE) { uid = (uint32_t)uniq.size(); uniq.push_back(key); }
+        auto it = where.find(key);
+        if (it == where.end()) {
+            if (hg.empty() || hg.back().uniq.size() == KMP_MULTI_MAX_UNIQUE) hg.emplace_back();
+            it = where.emplace(key, std::make_pair((uint32_t)hg.size() - 1u, (uint32_t)hg.back().uniq.size())).first;
+            hg.back().uniq.push_back(key);
         }
-        if (uid != UINT32_MAX) { multi_ids.push_back(i); multi_rows.push_back(uid); }
-        else (m >= 4 ? rest_l : rest_s).push_back(i);
+        hg[it->second.first].ids.push_back(i);
+        hg[it->second.first].rows.push_back(it->second.second);
     }
-    if (uniq.size() >= 2) {
-        const uint32_t U = (uint32_t)uniq.size();
+    if (where.size() < 2) {                       /* nothing to fuse: every pattern keeps its own pass (c->d_ids) */
+        return KMPGPU_OK;
+    }
+    for (const HostGroup &h : hg) {
+        const uint32_t U = (uint32_t)h.uniq.size();
         std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)U * KMP_MULTI_REC_WORDS, 0u);
         uint16_t *bucket = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_BUCKET_W0);
         uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
         std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
         for (uint32_t u = 0; u < U; u++) {
-            const std::string &p = uniq[u];
+            const std::string &p = h.uniq[u];
             const uint32_t w16 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8);
             for (uint32_t t = 0; t < 256u; t++) {                     /* a 2-byte pattern matches whatever follows it */
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : t;
@@ -562,38 +584,41 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             rec[10] = (uint32_t)p.size();
         }
         uint32_t pos = 0;
-        for (uint32_t h = 0; h < KMP_MULTI_BUCKETS; h++) {
-            if (lists[h].empty()) { bucket[h] = 0xFFFFu; continue; }
-            bucket[h] = (uint16_t)pos;
-            for (size_t q = 0; q < lists[h].size(); q++) {
-                const std::string &p = uniq[lists[h][q]];
+        for (uint32_t hh = 0; hh < KMP_MULTI_BUCKETS; hh++) {
+            if (lists[hh].empty()) { bucket[hh] = 0xFFFFu; continue; }
+            bucket[hh] = (uint16_t)pos;
+            for (size_t q = 0; q < lists[hh].size(); q++) {
+                const std::string &p = h.uniq[lists[hh][q]];
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : 0u;      /* never 0x00 inside a pattern */
-                entry[pos++] = lists[h][q] | (third << 8) | (q + 1 == lists[h].size() ? 0x80000000u : 0u);
+                entry[pos++] = lists[hh][q] | (third << 8) | (q + 1 == lists[hh].size() ? 0x80000000u : 0u);
             }
         }
-        std::vector<uint32_t> rest(rest_l);
-        rest.insert(rest.end(), rest_s.begin(), rest_s.end());
-        HIP_TRY(hipMalloc(&c->d_multi_tables, tab.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_multi_ids, multi_ids.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_multi_rows, multi_rows.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_rest_ids, (rest.size() ? rest.size() : 1) * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(c->d_multi_tables, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_multi_ids, multi_ids.data(), multi_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_multi_rows, multi_rows.data(), multi_rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) */
-        std::vector<uint32_t> uid_first(U + 1, 0u), uid_ids(multi_ids.size());
-        for (uint32_t r : multi_rows) uid_first[r + 1]++;
+        std::vector<uint32_t> uid_first(U + 1, 0u), uid_ids(h.ids.size());
+        for (uint32_t r : h.rows) uid_first[r + 1]++;
         for (uint32_t u = 0; u < U; u++) uid_first[u + 1] += uid_first[u];
         { std::vector<uint32_t> fill(uid_first.begin(), uid_first.end() - 1);
-          for (size_t i = 0; i < multi_ids.size(); i++) uid_ids[fill[multi_rows[i]]++] = multi_ids[i]; }
-        HIP_TRY(hipMalloc(&c->d_uid_first, uid_first.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_uid_ids, uid_ids.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(c->d_uid_first, uid_first.data(), uid_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_uid_ids, uid_ids.data(), uid_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (!rest.empty()) HIP_TRY(hipMemcpy(c->d_rest_ids, rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->multi_words = (uint32_t)tab.size(); c->n_multi_unique = U; c->n_multi = (uint32_t)multi_ids.size();
-        c->rest_long = (uint32_t)rest_l.size(); c->rest_short = (uint32_t)rest_s.size();
+          for (size_t i = 0; i < h.ids.size(); i++) uid_ids[fill[h.rows[i]]++] = h.ids[i]; }
+        c->fused_groups.emplace_back();
+        kmpgpu_ctx::FusedGroup &g = c->fused_groups.back();
+        auto up = [&](uint32_t **d, const std::vector<uint32_t> &v) -> hipError_t {
+            hipError_t e = hipMalloc(d, (v.size() ? v.size() : 1) * sizeof(uint32_t));
+            if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            return e;
+        };
+        HIP_TRY(up(&g.d_tables, tab));
+        HIP_TRY(up(&g.d_ids, h.ids));
+        HIP_TRY(up(&g.d_rows, h.rows));
+        HIP_TRY(up(&g.d_uid_first, uid_first));
+        HIP_TRY(up(&g.d_uid_ids, uid_ids));
+        g.words = (uint32_t)tab.size(); g.n_unique = U; g.n_ids = (uint32_t)h.ids.size();
+        c->n_multi_unique += U;
     }
+    std::vector<uint32_t> rest(rest_l);
+    rest.insert(rest.end(), rest_s.begin(), rest_s.end());
+    HIP_TRY(hipMalloc(&c->d_rest_ids, (rest.size() ? rest.size() : 1) * sizeof(uint32_t)));
+    if (!rest.empty()) HIP_TRY(hipMemcpy(c->d_rest_ids, rest.data(), rest.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->rest_long = (uint32_t)rest_l.size(); c->rest_short = (uint32_t)rest_s.size();
     return KMPGPU_OK;
 }
 

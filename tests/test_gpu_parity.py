@@ -314,8 +314,19 @@ def test_fused_multi_pattern_edge_cases(gm, oracle):
         payloads.append(bytes(b))
     check_payloads(gm, oracle, payloads, pats, variants=((MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_AUTO)))
     check_payloads(gm, oracle, [p[:1500].ljust(1500, b"a") for p in payloads], pats, variants=((MODE_FILTER, KERNEL_FUSED),))
-    many = [bytes([97 + (i % 3), 97 + (i // 3) % 3, 97 + (i // 9) % 3, 97 + (i // 27) % 3, 97 + (i // 81) % 3, 97 + (i // 243) % 3]) for i in range(300)]
+    # more distinct patterns than one table set holds (256): the fused pass runs once per group of 256
+    many = [bytes([97 + (i % 3), 97 + (i // 3) % 3, 97 + (i // 9) % 3, 97 + (i // 27) % 3, 97 + (i // 81) % 3, 97 + (i // 243) % 3]) for i in range(700)]
+    many += many[5:9] + [b"abc", b"b" * 30]
     check_payloads(gm, oracle, payloads[:200], many, variants=((MODE_FILTER, KERNEL_FUSED),))
+    arena = K.HostArena.from_payloads(payloads[:60])
+    want, _ = oracle.count(arena.bytes, arena.off, arena.len, many)
+    gm.set_option(OPT_MODE, MODE_FILTER); gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 1)
+    gm.set_patterns(many); gm.load_arena(arena)
+    recs, found, cnts = gm.scan_offsets(int(want.sum()) + 1)
+    assert found == int(want.sum()) == len(recs) and cnts.tolist() == want.tolist()
+    per = np.bincount(recs["pattern"].astype(np.int64), minlength=len(many))
+    assert per.tolist() == want.tolist()
+    gm.set_option(OPT_FUSED, 2)
 
 
 def test_fused_binary_text(gm, oracle):
