@@ -63,10 +63,11 @@ typedef struct kmpgpu_match {
 #define KMPGPU_OPT_MODE          1   /* 0 auto (filter + KMP verify), 1 KMP automaton only */
 #define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this; 0 = auto (default)    */
 #define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8; 0 = auto */
-#define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: every pattern of 2..20
-                                        bytes is counted in ONE read of a packed arena (the
-                                        others keep one read per pattern); 0 = off; 2 = auto
-                                        (default): fused from 3 such unique patterns on       */
+#define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: the patterns of 2..99
+                                        bytes are counted in ONE read of a packed arena per 256
+                                        distinct patterns (1-byte patterns keep one read each);
+                                        0 = off; 2 = auto (default): fused from 3 such unique
+                                        patterns on                                            */
 #define KMPGPU_OPT_KERNEL        5   /* 0 auto: slots back to back -> packed streaming kernel, or
                                         the flat streaming kernel when every payload has the same
                                         length of 512 bytes or more (also taken for equal slots

@@ -30,12 +30,14 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
  * the host (kmpgpu_set_patterns) and copied into LDS by every block:
  *   [0, 512)         1024 x uint16: first entry of the bucket hash(b0 | b1 << 8), 0xFFFF = empty
  *   [512, 1024)      entries, uint32 each: unique-pattern id (bits 0-7) | third pattern byte << 8 (0 when the
- *                    pattern has 2 bytes: nothing to pre-check) | 0x80000000 on the last entry of a bucket
+ *                    pattern has 2 bytes: nothing to pre-check) | 0x40000000 for a pattern of more than 20 bytes |
+ *                    0x80000000 on the last entry of a bucket
  *   [1024, 3072)     64 Kbit filter over the first THREE text bytes: bit h = KMP_MULTI_BIT(b0 | b1 << 8 |
  *                    b2 << 16) (byte h >> 3, bit h & 7) is set for every pattern of 3+ bytes, and for all 256
  *                    values of b2 for a 2-byte pattern (so one lookup serves both).  The multiplicative
  *                    hash also spreads text, whose bytes share their high bits, over the LDS banks.
- *   [3072, ...)      one 12-word record per unique pattern: 5 pattern dwords, 5 byte masks, m, 0
+ *   [3072, ...)      one 12-word record per unique pattern: its first 20 bytes as 5 dwords, 5 byte masks, m, and for a
+ *                    pattern of more than 20 bytes its index + 1 (the rest is compared against kmp_pattern_dev.pat)
  * The first 3072 words live in static LDS (their offsets fold into the ds_read offset field). */
 #define KMP_MULTI_BUCKETS     1024u
 #define KMP_MULTI_BUCKET_W0   0u
@@ -46,7 +48,9 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_REC_WORDS   12u
 #define KMP_MULTI_MAX_UNIQUE  256u
 #define KMP_MULTI_MIN_LEN     2u
-#define KMP_MULTI_MAX_LEN     20u
+#define KMP_MULTI_PREFIX      20u      /* bytes of a pattern held in its record */
+#define KMP_MULTI_MAX_LEN     99u
+#define KMP_MULTI_WIN_WORDS   (KMP_CHUNK / 4u + 28u)     /* per-wavefront LDS window: the chunk + 112 bytes of the next one */
 #define KMP_MULTI_BIT(w24)    ((((uint32_t)(w24) & 0xFFFFFFu) * 0x9E3779u) >> 16)   /* v_mul_u32_u24, 16-bit hash */
 #define KMP_MULTI_HASH(w16)   ((((uint32_t)(w16) * 0x9E3Bu) >> 6) & (KMP_MULTI_BUCKETS - 1u))
 

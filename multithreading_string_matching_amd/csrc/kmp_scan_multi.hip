@@ -13,7 +13,7 @@
 namespace {
 
 /* ================================================================================================
- * Fused multi-pattern pass: every pattern of 2..20 bytes in ONE read of a packed
+ * Fused multi-pattern pass: every pattern of 2..99 bytes in ONE read of a packed
  * arena -- the reference re-reads every payload once per pattern (serial.c:154, openmp_data.c:163).
  *
  * Same streaming skeleton as kmp_scan_packed_kernel (buffer-load ring, packet-start bitmap, byte-
@@ -33,7 +33,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,
                       unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
-                      const uint32_t *__restrict__ uid_ids)
+                      const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
      * into the ds_read offset field; records, counters and one chunk window per wavefront follow dynamically */
@@ -121,6 +121,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 
                     /* rem: payload bytes left from this lane's first byte */
                     int32_t rem;
+                    uint64_t sg_all = 0ull, nx_all = 0ull;      /* CLEAN: start bits of this chunk (not cut at the range's end) and of the next */
                     if constexpr (CLEAN) {
                         /* Slot padding is all 0x00 (kmp_check_padding_kernel), so the payload's end can be replaced by
                          * the slot's end: a window that reaches into the padding holds a 0x00 and matches nothing.
@@ -133,6 +134,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                         const bool next1 = __builtin_amdgcn_inverse_ballot_w64((sg >> 1) | (nx << 63));     /* lane + 1 starts a packet */
                         const bool next2 = __builtin_amdgcn_inverse_ballot_w64((sg >> 2) | (nx << 62));     /* lane + 2 does            */
                         rem = next1 ? 16 : next2 ? 32 : (1 << 20);
+                        sg_all = sg; nx_all = nx;
                     } else {
                         /* from the index: uniform loop over the packet starts of the chunk (<= 0: slot padding) */
                         rem = remc - (int32_t)vo0;
@@ -169,9 +171,9 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                             /* level 2.  Stage the chunk + 32 bytes of halo in this wavefront's LDS window so that a
                              * lane can fetch the 20 bytes behind ANY of its start offsets, then let every lane walk
                              * its own hits: iterations = the largest hit count of a lane, not 16. */
-                            uint32_t *win = s_win + wave * (KMP_CHUNK / 4u + 8u);
+                            uint32_t *win = s_win + wave * KMP_MULTI_WIN_WORDS;
                             *reinterpret_cast<uint4 *>(win + lane * 4u) = v;
-                            if (lane < 2u) *reinterpret_cast<uint4 *>(win + KMP_CHUNK / 4u + lane * 4u) = make_uint4(bn.x, bn.y, bn.z, bn.w);
+                            if (lane < 7u) *reinterpret_cast<uint4 *>(win + KMP_CHUNK / 4u + lane * 4u) = make_uint4(bn.x, bn.y, bn.z, bn.w);
                             while (ballot64(hm != 0u) != 0ull) {
                                 if (hm != 0u) {
                                     const uint32_t i = (uint32_t)__builtin_ctz(hm);
@@ -198,7 +200,27 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                                 diff |= (__builtin_amdgcn_alignbyte(nx, prev, sa) ^ rec[d]) & rec[5 + d];
                                                 prev = nx;
                                             }
-                                            if (diff == 0u && (int32_t)(i + rec[10]) <= rem) {
+                                            bool hit = diff == 0u && (int32_t)(i + rec[10]) <= rem;
+                                            if (hit && (ent & 0x40000000u)) {
+                                                /* a pattern of more than 20 bytes whose first 20 matched: exact room up to the slot's end
+                                                 * (CLEAN: rem only tells 16 / 32 / more), then the remaining bytes, text from the LDS
+                                                 * window, pattern from its kmp_pattern_dev */
+                                                const uint32_t m = rec[10];
+                                                if constexpr (CLEAN) {
+                                                    const uint64_t above = (sg_all >> 1) >> lane;
+                                                    uint32_t d = 4096u;
+                                                    if (above != 0ull) d = (uint32_t)__builtin_ctzll(above) + 1u;
+                                                    else if (nx_all != 0ull) d = 64u - lane + (uint32_t)__builtin_ctzll(nx_all);
+                                                    hit = i + m <= d * KMP_LANE_BYTES;
+                                                }
+                                                if (hit) {
+                                                    const uint8_t *pp = patterns[rec[11] - 1u].pat;
+                                                    const uint8_t *tw = reinterpret_cast<const uint8_t *>(win) + o;
+                                                    for (uint32_t b = KMP_MULTI_PREFIX; b < m; ++b)
+                                                        if (tw[b] != pp[b]) { hit = false; break; }
+                                                }
+                                            }
+                                            if (hit) {
                                                 atomicAdd(&s_cnt[uid], 1u);
                                                 if constexpr (EMIT) {
                                                     /* which packet, and how far into it: from the start bitmap (the packet that
@@ -249,10 +271,10 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
-    const size_t lds = ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * (KMP_CHUNK / 4u + 8u)) * sizeof(uint32_t);
+    const size_t lds = ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * KMP_MULTI_WIN_WORDS) * sizeof(uint32_t);
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
 #define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
-        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, a.partials, em, uid_first, uid_ids)
+        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, a.partials, em, uid_first, uid_ids, a.patterns)
     if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, false, true); }
     else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true, false); else KMP_MULTI_LAUNCH(false, true, false); }
     else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false, false); else KMP_MULTI_LAUNCH(false, false, false); }

@@ -562,6 +562,8 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     }
     for (const HostGroup &h : hg) {
         const uint32_t U = (uint32_t)h.uniq.size();
+        std::vector<uint32_t> where_first(U, UINT32_MAX);                         /* a pattern index for every row */
+        for (size_t i = 0; i < h.ids.size(); i++) where_first[h.rows[i]] = std::min(where_first[h.rows[i]], h.ids[i]);
         std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)U * KMP_MULTI_REC_WORDS, 0u);
         uint16_t *bucket = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_BUCKET_W0);
         uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
@@ -577,11 +579,12 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             }
             lists[KMP_MULTI_HASH(w16)].push_back(u);
             uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)u * KMP_MULTI_REC_WORDS;
-            for (uint32_t b = 0; b < p.size(); b++) {
+            for (uint32_t b = 0; b < p.size() && b < KMP_MULTI_PREFIX; b++) {
                 rec[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
                 rec[5 + (b >> 2)] |= 0xFFu << (8 * (b & 3));
             }
             rec[10] = (uint32_t)p.size();
+            if (p.size() > KMP_MULTI_PREFIX) rec[11] = where_first[u] + 1u;       /* the rest of it: kmp_pattern_dev[that index].pat */
         }
         uint32_t pos = 0;
         for (uint32_t hh = 0; hh < KMP_MULTI_BUCKETS; hh++) {
@@ -590,7 +593,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             for (size_t q = 0; q < lists[hh].size(); q++) {
                 const std::string &p = h.uniq[lists[hh][q]];
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : 0u;      /* never 0x00 inside a pattern */
-                entry[pos++] = lists[hh][q] | (third << 8) | (q + 1 == lists[hh].size() ? 0x80000000u : 0u);
+                entry[pos++] = lists[hh][q] | (third << 8) | (p.size() > KMP_MULTI_PREFIX ? 0x40000000u : 0u) | (q + 1 == lists[hh].size() ? 0x80000000u : 0u);
             }
         }
         /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) */

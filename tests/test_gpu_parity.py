@@ -297,11 +297,12 @@ def test_empty_inputs(gm, oracle):
 
 
 def test_fused_multi_pattern_edge_cases(gm, oracle):
-    """The fused pass: duplicates, prefixes of each other, shared 2-byte prefixes (one bucket),
-    1-byte and > 20-byte patterns that fall back to the per-pattern kernels, 256+ unique patterns."""
+    """The fused pass: duplicates, prefixes of each other, shared 2-byte prefixes (one bucket), patterns of more than
+    20 bytes (record prefix + tail compare), 1-byte patterns that keep their own pass, 256+ unique patterns."""
     rng = random.Random(31)
     pats = [b"ab", b"abc", b"abca", b"abcab", b"ab", b"abcabcabcabcabcabcab", b"abcabcabcabcabcabcabc", b"a", b"ba", b"bab", b"cc",
-            b"ccc", b"cccc", b"c" * 20, b"c" * 21, b"bca" * 30, b"abc", b"ca"]
+            b"ccc", b"cccc", b"c" * 20, b"c" * 21, b"bca" * 30, b"abc", b"ca", b"c" * 99, b"c" * 40, b"c" * 21, b"abc" * 33,
+            b"abcabcabcabcabcabcabcb", b"c" * 20 + b"a", b"c" * 20 + b"b" * 5]
     payloads = []
     for k in range(600):
         L = rng.choice([0, 1, 2, 3, 19, 20, 21, 64, 500, 1024, 1500, 3000])
@@ -309,8 +310,9 @@ def test_fused_multi_pattern_edge_cases(gm, oracle):
         if L and rng.random() < 0.35:
             b[rng.randrange(L)] = 0
         if L > 200 and rng.random() < 0.3:
-            s0 = rng.randrange(0, L - 100)
-            b[s0:s0 + 90] = b"c" * 90
+            run = rng.choice([90, 99, 100, 130])
+            s0 = rng.randrange(0, L - run)
+            b[s0:s0 + run] = b"c" * run
         payloads.append(bytes(b))
     check_payloads(gm, oracle, payloads, pats, variants=((MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_AUTO)))
     check_payloads(gm, oracle, [p[:1500].ljust(1500, b"a") for p in payloads], pats, variants=((MODE_FILTER, KERNEL_FUSED),))
