@@ -160,6 +160,22 @@ class RefLib:
             f.restype = C.c_void_p
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
+        self.has_driver = hasattr(L, "kmpref_count_arena")
+        if self.has_driver:
+            L.kmpref_count_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int]
+            L.kmpref_count_arena.restype = C.c_longlong
+
+    def count_arena(self, arena: np.ndarray, off: np.ndarray, ln: np.ndarray, pattern: bytes, threads: int) -> Tuple[int, float]:
+        """(count, seconds): the reference's own kmp_matcher (serial.c:190-215) once per payload, the calls spread over
+        OpenMP threads as in openmp_data.c:157-175.  strlen() needs a 0x00 behind every payload inside its slot."""
+        import time
+        assert self.has_driver and b"\0" not in pattern and len(pattern) >= 1
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ends = off + np.asarray(ln, dtype=np.uint64)
+        assert np.all(np.asarray(ln) % 16 != 0) and not np.any(arena[ends.astype(np.int64)]), "a payload is not NUL-terminated inside its slot"
+        t = time.perf_counter()
+        c = self.lib.kmpref_count_arena(arena.ctypes.data, off.ctypes.data, len(off), pattern, int(threads))
+        return int(c), time.perf_counter() - t
 
     def kmp_prefix(self, pat: bytes) -> List[int]:
         assert len(pat) >= 1 and b"\0" not in pat

@@ -129,6 +129,26 @@ def test_extract_against_reference_object_code(oracle, reflib):
         assert oracle.dump(bytes(frame), None, "udp") == reflib.dump(bytes(frame), None, "udp")
 
 
+def test_reference_driver_equals_oracle_on_benchmark_arena(oracle, reflib):
+    """bench.py's "reference" CPU baseline: the reference's own kmp_matcher, one call per payload of the benchmark
+    arena (1500-byte payloads, zero-padded 1504-byte slots), must count what the restatement counts."""
+    import multithreading_string_matching_amd as K
+    if not reflib.has_driver:
+        pytest.skip("oracle/_ref/libkmpref.so predates the baseline driver")
+    n, L = 3000, 1500
+    needle = b"NEEDLE_16B_PATRN"
+    sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100)
+    off, ln, nbytes = K.arena_layout(None, L, n)
+    host = np.zeros(nbytes, dtype=np.uint8)
+    K.synth_fill_host(host, off, ln, sp, threads=2)
+    want, _ = oracle.count(host, off, ln, [needle, b"ab"], threads=2)
+    for pat, w in zip([needle, b"ab"], want):
+        for threads in (1, 3):
+            got, _ = reflib.count_arena(host, off, ln, pat, threads)
+            assert got == int(w)
+    assert int(want[0]) == K.synth_count_planted(sp, n, L)
+
+
 def test_openmp_equals_serial_on_random_arena(oracle):
     rng = np.random.default_rng(3)
     n = 2000
