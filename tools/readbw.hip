@@ -114,6 +114,28 @@ __global__ void __launch_bounds__(256) read_pktil(const u32x4 *__restrict__ src,
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
 }
 
+// contiguous range per wavefront as read_range, block size as a parameter (does the number of workgroups to
+// dispatch matter for the ramp-up of a 230 us launch?)
+template <int INFL, bool NT, int BS>
+__global__ void __launch_bounds__(BS) read_range_bs(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nw = (uint64_t)gridDim.x * (BS / 64), gw = (uint64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    const uint64_t chunks = n16 / 64u, per = (chunks + nw - 1) / nw;
+    const uint64_t c0 = gw * per, c1 = std::min(chunks, c0 + per);
+    u32x4 acc = {0, 0, 0, 0};
+    uint64_t c = c0;
+    for (; c + INFL <= c1; c += INFL) {
+        u32x4 v[INFL];
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) v[i] = ld16<NT>(src + (c + i) * 64u + lane);
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) acc ^= v[i];
+    }
+    for (; c < c1; ++c) acc ^= ld16<NT>(src + c * 64u + lane);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 // tile-interleaved: tile t (TILE consecutive 1 KiB chunks, all in flight at once) goes to wavefront t % nwaves
 template <int TILE, bool NT>
 __global__ void __launch_bounds__(256) read_tiles(const u32x4 *__restrict__ src, uint64_t n16, uint32_t *out)
@@ -259,8 +281,14 @@ int main()
         printf("ranges from %4d counters, %2d per wavefront   blocks/CU=4  %7.1f us  %6.0f GB/s\n", G, parts, us2, bytes / us2 / 1e3); fflush(stdout); } while (0)
         for (int parts : {2, 3, 4, 8}) { STEAL(64, parts); STEAL(256, parts); STEAL(1024, parts); }
     }
+    // block size: the same 3072 / 4096 wavefronts as 64..1024-thread workgroups
+    for (int waves : {3072, 4096}) {
+#define RUNBS(BS) do { const int b_ = waves * 64 / BS; double us = sustained_us([&] { hipLaunchKernelGGL((read_range_bs<4, true, BS>), dim3(b_), dim3(BS), 0, 0, s, n16, out); }); \
+        printf("range/wave 4 in flight nt, %4d wavefronts as %4d blocks of %4d threads  %7.1f us  %6.0f GB/s\n", waves, b_, BS, us, bytes / us / 1e3); fflush(stdout); } while (0)
+        RUNBS(64); RUNBS(128); RUNBS(256); RUNBS(512); RUNBS(1024);
+    }
     // tile-interleaved patterns against contiguous ranges, over the number of resident blocks
-    for (int blocks : {cus * 2, cus * 5 / 2, cus * 3, cus * 7 / 2, cus * 4, cus * 5, cus * 6}) {
+    for (int blocks : {cus * 3, cus * 4}) {
 #define RUNB(name, kern) do { double us = sustained_us([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, s, n16, out); }); \
         printf("%-42s blocks=%4d  %7.1f us  %6.0f GB/s\n", name, blocks, us, bytes / us / 1e3); fflush(stdout); } while (0)
         RUNB("range/wave 4 in flight nt", (read_range<4, true>));
