@@ -22,8 +22,9 @@ while time.time() - t0 < budget:
     rng = random.Random(seed)
     alpha = rng.choice([b"ab", b"abc", b"abcdefgh", bytes(range(1, 256)), b"ht p:/\r\n", b"aab"])
     uniform = rng.random() < 0.4
-    Lmax = rng.choice([20, 40, 130, 300, 1100, 1500, 2600, 5000])
-    n = rng.choice([1, 2, 7, 65, 300, 900, 3000])
+    big = os.environ.get("SOAK_BIG") == "1"          # fewer, larger cases: long payloads, many packets per wavefront range
+    Lmax = rng.choice([3000, 9000, 20000, 70000] if big else [20, 40, 130, 300, 1100, 1500, 2600, 5000])
+    n = rng.choice([50, 300, 2000] if big else [1, 2, 7, 65, 300, 900, 3000])
     nul_p = rng.choice([0.0, 0.0, 0.002, 0.05, 0.3])
     L0 = rng.randrange(0, Lmax)
     nz = [x for x in alpha if x]
