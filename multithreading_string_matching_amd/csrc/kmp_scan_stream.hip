@@ -4,22 +4,25 @@
  * kernel function kmp_matcher (serial.c:190-215).  Hand-written for 64-lane wavefronts; no MFMA
  * (byte scan, HBM-bound).
  *
- * Shape of the scan kernel
- *   - one packet per wavefront at a time; a persistent grid strides over the packets;
- *   - a packet is read in 1 KiB chunks: one global_load_dwordx4 per lane, perfectly coalesced,
- *     DEPTH chunk loads in flight per wavefront (register ring), packets pipelined back to back;
- *   - the pattern and its KMP failure table are staged in LDS once per block;
- *   - per chunk, every lane tests its 16 start offsets with a 4-byte SWAR compare against the
- *     pattern's first dword (halo dword from the next lane by DPP wave_shl:1) and looks for a
- *     0x00 byte with the has-zero trick; both results are wave-reduced with ballots;
- *   - the common case (no candidate in the chunk) ends there.  Otherwise the candidates are
- *     confirmed: patterns of <= 4 bytes are already exact; longer ones run the KMP automaton
- *     (LDS pattern + failure table) over the lane's 16 + m - 1 bytes, all in registers, the halo
- *     arriving by repeated wave_shl:1 shifts;
- *   - the reference's strlen() rule (serial.c:191): a start offset s counts only if
- *     s + m <= E, E = min(len, first 0x00).  A chunk that holds the first NUL ends the packet.
- *   - counts: per-lane -> wave -> block, one partial per (block, pattern), summed by
- *     kmp_reduce_kernel (no atomics, deterministic).
+ * Shape of the streaming kernels (flat: uniform stride, packed: any lengths)
+ *   - a persistent grid; every wavefront owns ONE contiguous byte range of the arena (whole packets) and
+ *     streams it in 1 KiB chunks: one buffer_load_dwordx4 per lane (16 B), perfectly coalesced, DEPTH
+ *     chunk loads in flight per wavefront in a register ring driven by hand-counted s_waitcnt vmcnt(N)
+ *     (kmp_dev_common.h: ring_wait / flat_issue); the buffer resource's record count makes the tail
+ *     chunk read zeros, so there is no clamping and no lane mask;
+ *   - still one packet per wavefront at a time: the packets of a range are scanned in order by the same
+ *     wavefront, which keeps the strlen() rule (serial.c:191) wave-local state;
+ *   - per chunk, every lane tests its 16 start offsets with a 4-byte compare against the pattern's first
+ *     dword (halo dword from the next lane by DPP wave_shl:1), reduced with v_min3 per group of four
+ *     offsets, and looks for 0x00 bytes with the has-zero trick; three ballots (zero lanes, packet-start
+ *     lanes, candidate lanes); the common case -- no candidate in the chunk -- ends there;
+ *   - rare path: per lane the largest start index that still counts (window inside the payload, no 0x00
+ *     before it); patterns of <= 4 bytes are exact after the filter, 5..20 bytes with few candidate lanes
+ *     are compared dword-wise from registers, everything else runs the KMP automaton (pattern + failure
+ *     table in LDS, text bytes from registers) -- the literal kmp_matcher (serial.c:190-215);
+ *   - a start offset s counts iff s + m <= E, E = min(len, first 0x00);
+ *   - counts: per-lane -> wave -> block, one partial per (block, pattern), summed by kmp_reduce_kernel
+ *     (no atomics, deterministic).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
