@@ -8,7 +8,7 @@ import torch
 import multithreading_string_matching_amd as K
 from multithreading_string_matching_amd.matcher import GpuMatcher, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_KERNEL
 
-n = 1_000_000
+n = int(os.environ.get("KMP_N", "1000000"))
 sp = K.SynthParams.make(seed=1234, needle=b"NEEDLE_16B_PATRN", plant_permille=100)
 m = GpuMatcher(0)
 rng = np.random.default_rng(4)
