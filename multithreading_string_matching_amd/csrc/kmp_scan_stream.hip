@@ -63,6 +63,25 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
     __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
 
+    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
+    const uint32_t wave = sgpr(threadIdx.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
+    /* this wavefront's packets [k0, k1) = bytes [0, range) behind base */
+    const uint64_t k0 = gw * pkts_per_wave;
+    const uint64_t k1 = min(n_pkts, k0 + pkts_per_wave);
+    const uint32_t range = (k0 < n_pkts) ? (uint32_t)(k1 - k0) * stride : 0u;      /* host guarantees < 2^31 */
+    const uint8_t *base = arena + ((k0 < n_pkts) ? k0 * (uint64_t)stride : 0ull);
+    const uint32_t step_mod = KMP_CHUNK % stride;                                    /* p0 advance per chunk (mod stride) */
+
+    /* The stream starts before anything else: the first DEPTH chunk loads need nothing but the range, and the
+     * 2 us they take cover the fetch of the pattern record below (an empty range has a record count of 0: its
+     * loads fetch nothing and return zeros). */
+    const i32x4    rsrc = make_rsrc(base, range);
+    const uint32_t vo0 = lane * KMP_LANE_BYTES;
+    u32x4 buf[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+
     const uint32_t pid = pat_ids[blockIdx.y];
     const kmp_pattern_dev *gp = patterns + pid;
     if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
@@ -71,25 +90,10 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
 
     const PatConst pc = load_pat_const(gp);
     const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
-    const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
-    const uint32_t wave = sgpr(threadIdx.x >> 6);
-    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
     if (EMIT) em.pattern = pid;
-    /* this wavefront's packets [k0, k1) = bytes [0, range) behind base */
-    const uint64_t k0 = gw * pkts_per_wave;
-    const uint64_t k1 = min(n_pkts, k0 + pkts_per_wave);
-    const uint32_t range = (k0 < n_pkts) ? (uint32_t)(k1 - k0) * stride : 0u;      /* host guarantees < 2^31 */
-    const uint8_t *base = arena + ((k0 < n_pkts) ? k0 * (uint64_t)stride : 0ull);
-    const uint32_t step_mod = KMP_CHUNK % stride;                                    /* p0 advance per chunk (mod stride) */
 
     uint32_t cnt = 0u;
-    if (range) {
-        const i32x4    rsrc = make_rsrc(base, range);
-        const uint32_t vo0 = lane * KMP_LANE_BYTES;
-        u32x4 buf[DEPTH];
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
-
+    {
         uint32_t p0 = vo0 % stride;          /* offset of this lane's first byte inside its packet's slot */
         bool     dead = false;               /* the packet that enters the chunk already had a 0x00      */
         uint32_t cb = 0u;                    /* byte offset of the chunk being consumed                   */

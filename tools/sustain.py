@@ -15,7 +15,7 @@ d_arena = torch.zeros(n * 1504 + 64, dtype=torch.uint8, device="cuda")
 d_off = torch.empty(n, dtype=torch.int64, device="cuda"); d_len = torch.empty(n, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize(); m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp); m.sync()
 m.set_patterns([b"NEEDLE_16B_PATRN"]); m.attach_arena(d_arena, d_off, d_len)
-cfgs = [(0, 4, 4), (0, 4, 3), (0, 3, 6), (0, 4, 6), (0, 6, 4), (2, 3, 6), (2, 4, 4)]
+cfgs = [(0, 4, 4), (0, 4, 3), (2, 3, 6), (2, 4, 4)]
 N = 400
 res = {}
 for rnd in range(2):
