@@ -43,14 +43,6 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     uint32_t *s_rec = s_dyn;
     uint32_t *s_cnt = s_dyn + rec_words;
     uint32_t *s_win = s_dyn + ((rec_words + n_unique + 3u) & ~3u);
-    for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0; i += KMP_BLOCK_THREADS) s_fix[i] = tables[i];
-    for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
-    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
-    __syncthreads();
-    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_fix + KMP_MULTI_BUCKET_W0);
-    const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
-    const uint8_t  *s_filter = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
-
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
@@ -61,20 +53,31 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     const uint64_t off0 = off_first - pre;
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;
 
+    /* The stream starts before the tables are copied: the first DEPTH chunk loads need nothing but the range, and
+     * filling 16-30 KB of LDS from global memory takes longer than they do (an empty range has a record count of
+     * 0: its loads fetch nothing and return zeros). */
+    const i32x4    rsrc = make_rsrc(arena + off0, range);
+    const uint32_t vo0 = lane * KMP_LANE_BYTES;
+    u32x4 buf[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+
+    for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0; i += KMP_BLOCK_THREADS) s_fix[i] = tables[i];
+    for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
+    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
+    __syncthreads();
+    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_fix + KMP_MULTI_BUCKET_W0);
+    const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
+    const uint8_t  *s_filter = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
+
     if (range) {
-        const i32x4    rsrc = make_rsrc(arena + off0, range);
-        const uint32_t vo0 = lane * KMP_LANE_BYTES;
         const uint64_t b0 = off0 >> 4;
         const unsigned long long *bw = bitmap + (b0 >> 6);
         const uint32_t sh = (uint32_t)(b0 & 63ull);
 
-        u32x4 buf[DEPTH];
         unsigned long long hiw[DEPTH];
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {
-            flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
-            hiw[s] = bw[s + 1];
-        }
+        for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[s + 1];
         unsigned long long low = bw[0];
         uint64_t kcur = k0 - 1ull;           /* last packet that has started                                   */
         uint64_t kbase = k0 - 1ull;          /* EMIT: the same, kept in both variants of the payload-end logic */
@@ -254,9 +257,9 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                 ++j;
             }
         }
-#pragma unroll
-        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
     }
+#pragma unroll
+    for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);     /* nothing in flight when the wavefront ends */
 
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS)
