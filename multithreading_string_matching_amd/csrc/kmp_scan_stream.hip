@@ -206,18 +206,9 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
     __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
 
-    const uint32_t pid = pat_ids[blockIdx.y];
-    const kmp_pattern_dev *gp = patterns + pid;
-    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
-        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
-    __syncthreads();
-
-    const PatConst pc = load_pat_const(gp);
-    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
-    if (EMIT) em.pattern = pid;
     const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
     /* The range starts at a packet start (16-byte aligned).  Streaming from there would make every 1 KiB chunk
      * load straddle nine 128-byte lines instead of covering eight, and the line shared by two consecutive
@@ -229,23 +220,33 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
     const uint64_t off0 = off_first - pre;
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;    /* planner guarantees < 2^31 */
 
+    /* the stream starts before the pattern record is staged (see kmp_scan_flat_kernel); an empty range fetches nothing */
+    const i32x4    rsrc = make_rsrc(arena + off0, range);
+    const uint32_t vo0 = lane * KMP_LANE_BYTES;
+    u32x4 buf[DEPTH];
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+
+    const uint32_t pid = pat_ids[blockIdx.y];
+    const kmp_pattern_dev *gp = patterns + pid;
+    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
+        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
+    __syncthreads();
+
+    const PatConst pc = load_pat_const(gp);
+    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
+    if (EMIT) em.pattern = pid;
+
     uint32_t cnt = 0u;
     if (range) {
-        const uint8_t *base = arena + off0;
-        const i32x4    rsrc = make_rsrc(base, range);
-        const uint32_t vo0 = lane * KMP_LANE_BYTES;
         /* packet-start bits of chunk j: bits [b0 + 64 j, +64) of the bitmap = words wi0+j, wi0+j+1 shifted by sh */
         const uint64_t b0 = off0 >> 4;
         const unsigned long long *bw = bitmap + (b0 >> 6);
         const uint32_t sh = (uint32_t)(b0 & 63ull);
 
-        u32x4 buf[DEPTH];
         unsigned long long hiw[DEPTH];       /* bitmap word wi0 + j + 1 of the chunk in ring slot s, fetched one group ahead */
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {
-            flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
-            hiw[s] = bw[s + 1];
-        }
+        for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[s + 1];
         unsigned long long low = bw[0];      /* bitmap word wi0 + j of the chunk being consumed */
         uint64_t kbase = k0 - 1ull;          /* index of the last packet started before the chunk */
         bool     dead = false;
@@ -336,9 +337,9 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                 ++j;
             }
         }
-#pragma unroll
-        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
     }
+#pragma unroll
+    for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);     /* nothing in flight when the wavefront ends */
 
     unsigned long long c64 = cnt;
 #pragma unroll
