@@ -62,6 +62,167 @@ def host_cores() -> int:
     return n
 
 
+def extra_configs(m, dev, passes, headline, sample97):
+    """The other BASELINE configs and the rows VERDICT asks to see through a driver-timed command: each leg is
+    count-checked first, then `passes` back-to-back passes are timed with HIP events around the scan launches
+    (kmpgpu_profile_begin/end).  Returns a list of dicts; algorithmic bytes = sum of payload lengths, one read."""
+    import torch
+
+    import multithreading_string_matching_amd as K
+    from multithreading_string_matching_amd.matcher import (KERNEL_AUTO, KERNEL_GENERAL, MODE_AUTOMATON, MODE_FILTER, OPT_FUSED, OPT_KERNEL,
+                                                            OPT_MODE)
+
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    pats97 = K.load_patterns(os.path.join(data, "strings.txt"))
+    out = []
+
+    def timed(name, config, payload_bytes, check, note=None, settle=40):
+        for _ in range(settle):
+            m.scan_enqueue()
+        m.sync()
+        m.profile_begin(passes * 8)
+        for _ in range(passes):
+            m.scan_enqueue()
+        ms = m.profile_end(passes * 8)
+        per_pass = float(ms.sum()) / passes
+        gbs = payload_bytes / (per_pass * 1e-3) / 1e9
+        row = {"name": name, "config": config, "ms": round(per_pass, 5), "launches_per_pass": int(round(len(ms) / passes)),
+               "algorithmic_bytes": int(payload_bytes), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+               "count_check": check}
+        if note:
+            row["note"] = note
+        out.append(row)
+        log(f"extra {name}: {per_pass * 1e3:.1f} us/pass, {gbs:.0f} GB/s, frac {gbs / HBM_PEAK_GBS:.3f} ({check})")
+
+    def device_arena(lens, fixed_len, n, sp):
+        off, ln, nbytes = K.arena_layout(lens, fixed_len, n)
+        d_a = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        d_o = torch.from_numpy(off.astype(np.int64)).to(dev)
+        d_l = torch.from_numpy(ln.astype(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        m.synth_fill(d_a, d_o, d_l, sp)
+        m.sync()
+        return d_a, d_o, d_l, int(ln.astype(np.int64).sum())
+
+    # (1) strings.txt (97 patterns) over the headline arena: the multi-pattern outer loop serial.c:154 at HBM scale, fused pass
+    d_arena, d_off, d_len, n, plen = headline
+    m.set_option(OPT_FUSED, 0)
+    m.set_patterns(pats97)
+    m.attach_arena(d_arena, d_off, d_len)
+    per_pattern, _ = m.scan()                       # 97 single-pattern streaming passes: an independent implementation
+    m.set_option(OPT_FUSED, 2)
+    m.attach_arena(d_arena, d_off, d_len)
+    fused, _ = m.scan()
+    if fused.tolist() != per_pattern.tolist():
+        raise SystemExit("extra strings.txt x 1M x 1500 B: fused counts differ from the per-pattern passes")
+    check = "fused == 97 single-pattern passes over the full arena"
+    if sample97 is not None:
+        ns, want = sample97
+        m.attach_arena(d_arena, d_off[:ns], d_len[:ns])
+        got, _ = m.scan()
+        if got.tolist() != want:
+            raise SystemExit("extra strings.txt: fused counts on the oracle sample differ from the oracle")
+        check += f"; == oracle on the first {ns} packets"
+        m.attach_arena(d_arena, d_off, d_len)
+    timed("strings_txt_97_x_1m_1500B_fused", "BASELINE configs[2] pattern set (strings.txt, 97 tokens, 88 distinct) over configs[1]'s arena, "
+          "ONE read of the arena (kmp_scan_multi_kernel)", n * plen, check)
+    del d_arena, d_off, d_len, headline
+    m.set_patterns([NEEDLE])
+    m.attach_arena(torch.zeros(0, dtype=torch.uint8, device=dev), torch.zeros(0, dtype=torch.int64, device=dev),
+                   torch.zeros(0, dtype=torch.int32, device=dev))
+    torch.cuda.empty_cache()
+
+    # (2) BASELINE configs[4], per-GPU shape: 1 M payloads, lengths 64..9000 B Zipf(1.1) over the length ranks
+    rng = np.random.default_rng(4)
+    ranks = np.arange(1, 9000 - 64 + 2)
+    pz = 1.0 / ranks ** 1.1
+    pz /= pz.sum()
+    nz = 1_000_000
+    zl = (64 + rng.choice(len(ranks), size=nz, p=pz)).astype(np.uint32)
+    sp = K.SynthParams.make(seed=SEED, needle=NEEDLE, plant_permille=100)
+    d_a, d_o, d_l, pb = device_arena(zl, 0, nz, sp)
+    m.set_patterns([NEEDLE])
+    m.attach_arena(d_a, d_o, d_l)
+    want = K.synth_count_planted(sp, nz, 0, lens=zl)
+    got, _ = m.scan()
+    if int(got[0]) != want:
+        raise SystemExit(f"extra zipf: count {int(got[0])} != planted {want}")
+    timed("zipf_1m_64_9000B", "BASELINE configs[4] per-GPU shape: 1 M payloads, 64..9000 B Zipf(1.1), one 16-byte pattern in ~10 % of packets, "
+          "byte-balanced wavefront ranges (kmp_scan_packed_kernel)", pb, f"count == planted ({want})")
+    # the same arena under the 97 patterns
+    m.set_option(OPT_FUSED, 0)
+    m.set_patterns(pats97)
+    m.attach_arena(d_a, d_o, d_l)
+    per_pattern, _ = m.scan()
+    m.set_option(OPT_FUSED, 2)
+    m.attach_arena(d_a, d_o, d_l)
+    fused, _ = m.scan()
+    if fused.tolist() != per_pattern.tolist():
+        raise SystemExit("extra zipf x 97: fused counts differ from the per-pattern passes")
+    timed("zipf_1m_64_9000B_x_strings_txt_97_fused", "the same arena, strings.txt (97 patterns), fused pass", pb,
+          "fused == 97 single-pattern passes")
+    del d_a, d_o, d_l
+    torch.cuda.empty_cache()
+
+    # (3) BASELINE configs[2]: very_big_udp.pcap x strings.txt (and big_udp.pcap, whose counts are not all zero)
+    with open(os.path.join(ROOT, "tests", "golden", "fixture_counts.json")) as f:
+        golden = json.load(f)["fixtures"]
+    for fx in ("very_big_udp.pcap", "big_udp.pcap"):
+        a = K.HostArena.from_pcap(os.path.join(data, fx), "udp")
+        m.set_patterns(pats97)
+        m.load_arena(a)
+        got, _ = m.scan()
+        if got.tolist() != golden[f"{fx}:udp"]["counts"]:
+            raise SystemExit(f"extra {fx}: counts differ from the golden vector (serial.c's)")
+        timed(f"{fx.split('.')[0]}_x_strings_txt_97", f"BASELINE configs[2]: {fx} ({a.n_pkts} payloads) x strings.txt, fused pass",
+              a.payload_bytes, "== golden counts of serial.c (SURVEY App. B)",
+              note="1.3 MB / 0.6 MB of payload: cache-resident and launch-latency-bound, the HBM fraction is not meaningful here")
+
+    # (4) dense candidates in small packets: 64-byte payloads, needle in 10 % of them; lengths 34..328 B (very_big_udp.pcap's range)
+    for name, lo, hi, nn in (("small_64B_needle_10pct", 64, 64, 12_000_000), ("small_34_328B_needle_10pct", 34, 328, 4_000_000)):
+        lens = np.random.default_rng(5).integers(lo, hi + 1, size=nn).astype(np.uint32)
+        d_a, d_o, d_l, pb = device_arena(lens, 0, nn, sp)
+        m.set_patterns([NEEDLE])
+        m.attach_arena(d_a, d_o, d_l)
+        want = K.synth_count_planted(sp, nn, 0, lens=lens)
+        got, _ = m.scan()
+        if int(got[0]) != want:
+            raise SystemExit(f"extra {name}: count {int(got[0])} != planted {want}")
+        timed(name, f"{nn} payloads of {lo}..{hi} B, one 16-byte pattern in ~10 % of packets (a candidate in most 1 KiB chunks)", pb,
+              f"count == planted ({want})")
+        del d_a, d_o, d_l
+        torch.cuda.empty_cache()
+
+    # (5) worst cases for a filter-then-confirm scan: text that is a candidate everywhere
+    na, la = 200_000, 1500
+    for name, span, pat, closed in (("adversarial_all_a_x_a16", 1, b"a" * 16, na * (la - 15)),
+                                    ("adversarial_all_a_x_a15b", 1, b"a" * 15 + b"b", 0),
+                                    ("adversarial_all_a_x_a40", 1, b"a" * 40, na * (la - 39)),
+                                    ("adversarial_ab_x_abababababababab", 2, b"ab" * 8, None)):
+        spa = K.SynthParams.make(seed=SEED, needle=b"", plant_permille=0, lo=ord("a"), span=span)
+        d_a, d_o, d_l, pb = device_arena(None, la, na, spa)
+        m.set_patterns([pat])
+        m.attach_arena(d_a, d_o, d_l)
+        got, _ = m.scan()
+        if closed is None:
+            m.set_option(OPT_MODE, MODE_AUTOMATON)
+            m.set_option(OPT_KERNEL, KERNEL_GENERAL)
+            m.attach_arena(d_a, d_o, d_l)
+            ref, _ = m.scan()                        # the literal KMP automaton on every byte (kmp_scan_kernel MODE 1)
+            m.set_option(OPT_MODE, MODE_FILTER)
+            m.set_option(OPT_KERNEL, KERNEL_AUTO)
+            m.attach_arena(d_a, d_o, d_l)
+            ok, chk = int(got[0]) == int(ref[0]), f"== the KMP-automaton kernel ({int(ref[0])})"
+        else:
+            ok, chk = int(got[0]) == closed, f"== closed form ({closed})"
+        if not ok:
+            raise SystemExit(f"extra {name}: count {int(got[0])} fails its check {chk}")
+        timed(name, f"{na} x {la} B, text alphabet of {span} letter(s), pattern {pat.decode()!r}: every offset is a candidate", pb, chk)
+        del d_a, d_o, d_l
+        torch.cuda.empty_cache()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +234,9 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=0, help="chunk loads in flight per wavefront (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (Zipf lengths, strings.txt fused, pcap fixture, "
+                    "dense-candidate and adversarial inputs) that follow the timed headline region at N = 1")
+    ap.add_argument("--extra-passes", type=int, default=60)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: create the process group and run the all-reduce path "
                     "even with one rank (checks the RCCL plumbing on a 1-GPU box)")
@@ -208,6 +372,7 @@ def main() -> None:
 
     # ---- CPU baseline + sample parity (rank 0, N == 1) -------------------------------------------
     cpu = None
+    sample97 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         o = oracle.load()
@@ -256,7 +421,21 @@ def main() -> None:
                                   f"the reference's own kmp_matcher object code (serial.c:190-215) over the arena, one call per payload, "
                                   f"{cores} OpenMP threads (guided, as openmp_data.c:157-175), {rbest:.3f} s per pass; the port "
                                   f"(oracle/kmp_oracle.c, openmp_data.c:126-178 bracket) takes {best:.3f} s"})
+        # checker for the multi-pattern extra config: the oracle's counts of strings.txt's 97 patterns on the first packets
+        if not args.no_extra:
+            ns = min(n, 50_000)
+            pats97 = K.load_patterns(os.path.join(ROOT, "tests", "golden", "data", "strings.txt"))
+            c97, _ = o.count(host, off[:ns], ln[:ns], pats97, threads=cores)
+            sample97 = (ns, c97.tolist())
         del host
+
+    # ---- the other BASELINE configs, after the timed headline region (rank 0, N == 1) -----------------
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        headline = (d_arena, d_off, d_len, n, PAYLOAD_LEN)
+        del d_arena, d_off, d_len
+        extra = extra_configs(m, dev, args.extra_passes, headline, sample97)
+        del headline
 
     if rank == 0:
         bytes_all = payload_bytes * world * args.steps
@@ -286,10 +465,15 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (None if traffic is None else "profiles/roofline_traffic.json: FETCH_SIZE x 2 from a separate rocprofv3 --pmc "
+                                   "pass over this workload (tools/pmc.sh), a committed constant -- NOT measured by this run"),
+                "path": "filter path: the needle's alphabet is disjoint from the text's, candidates only where it was planted (10 % of the "
+                        "packets); extra_configs carries the dense-candidate and adversarial figures",
                 "kernel": "kmp_scan_flat_kernel", "launch_ms_avg": round(avg_launch_ms, 5),
                 "algorithmic_bytes_per_launch": payload_bytes,
             },
             "cpu_baseline": cpu,
+            "extra_configs": extra,
         }
         print(json.dumps(out), flush=True)
 

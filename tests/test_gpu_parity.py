@@ -597,6 +597,75 @@ def test_synth_zipf_with_nuls(gm, oracle):
     gm.set_stream(None)
 
 
+def _zipf_lengths(n, seed=4):
+    rng = np.random.default_rng(seed)
+    ranks = np.arange(1, 9000 - 64 + 2)
+    p = 1.0 / ranks ** 1.1
+    p /= p.sum()
+    return (64 + rng.choice(len(ranks), size=n, p=p)).astype(np.uint32)
+
+
+def test_full_size_zipf_1m(gm, oracle):
+    """BASELINE configs[4] at its per-GPU size: 1 M payloads of 64..9000 B, Zipf(1.1) over the length ranks, generated on
+    the device.  Size-independent checks: count == number of planted packets (closed form from the generator) on the
+    auto-selected, the packed and the fused kernels, several grid shapes (the byte-balanced wavefront plan changes with
+    the grid), the two halves of the arena add up; with NULs sprinkled in (p = 1e-3 per byte) every kernel family
+    agrees with every other at full size and with the oracle on the first 100 000 packets."""
+    import torch
+    n = 1_000_000
+    lens = _zipf_lengths(n)
+    lens[:5] = [9000, 8999, 64, 1024, 2048]
+    needle = b"NEEDLE_16B_PATRN"
+    pats = [needle, b"NEEDLE", b"PATRN"]
+    for nul_ppm in (0, 1000):
+        sp = K.SynthParams.make(seed=1234, needle=needle, plant_permille=100, nul_ppm=nul_ppm)
+        d_arena, d_off, d_len, off, ln, nbytes = _device_synth(gm, n, 0, sp, lens)
+        planted = K.synth_count_planted(sp, n, 0, lens=lens)
+        gm.set_option(OPT_MODE, MODE_FILTER)
+        gm.set_patterns(pats)
+        gm.attach_arena(d_arena, d_off, d_len)
+        assert gm.arena_info() == (n, int(lens.astype(np.int64).sum()))
+        results = {}
+        for kernel in (KERNEL_AUTO, KERNEL_PACKED, KERNEL_FUSED, KERNEL_GENERAL):
+            gm.set_option(OPT_KERNEL, KERNEL_AUTO if kernel == KERNEL_FUSED else kernel)
+            gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
+            for bpc in ((0, 3, 7) if kernel != KERNEL_GENERAL else (0,)):
+                gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+                got, _ = gm.scan()
+                results[(kernel, bpc)] = got.tolist()
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+        gm.set_option(OPT_FUSED, 2)
+        gm.set_option(OPT_BLOCKS_PER_CU, 0)
+        first = results[(KERNEL_AUTO, 0)]
+        assert all(v == first for v in results.values()), {k: v for k, v in results.items() if v != first}
+        if nul_ppm == 0:
+            assert first == [planted, planted, planted]      # the text is a..z: upper-case tokens occur only inside the planted needle
+        else:
+            assert 0 < first[0] < planted                    # a 0x00 before the needle ends the text first (serial.c:191)
+        # the two halves add up (mpi_dumping.c:149-157: counts are partition-invariant)
+        h = n // 2
+        gm.attach_arena(d_arena, d_off[:h], d_len[:h])
+        a = gm.scan()[0]
+        b0 = int(off[h])
+        sub_off = torch.from_numpy((off[h:] - off[h]).astype(np.int64)).cuda()
+        gm.attach_arena(d_arena[b0:], sub_off, d_len[h:])
+        b = gm.scan()[0]
+        assert (a + b).tolist() == first
+        # oracle on a slice that it finishes in seconds
+        ns = 100_000
+        end = int(off[ns])
+        host = d_arena[:end + 64].cpu().numpy()
+        want, _ = oracle.count(host, off[:ns], ln[:ns], pats, threads=8)
+        gm.attach_arena(d_arena, d_off[:ns], d_len[:ns])
+        for kernel in (KERNEL_AUTO, KERNEL_FUSED):
+            gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
+            assert gm.scan()[0].tolist() == want.tolist(), (nul_ppm, kernel)
+        gm.set_option(OPT_FUSED, 2)
+        gm.set_stream(None)
+        del d_arena, d_off, d_len, sub_off
+        torch.cuda.empty_cache()
+
+
 def test_full_size_property_1m(gm):
     """BASELINE configs[1] at full size: 1 M x 1500 B, one 16-byte pattern.  Size-independent
     checks: count == number of planted packets (closed form from the generator), identical for
