@@ -60,33 +60,6 @@ __device__ __forceinline__ void kmp_step(uint32_t ch, uint32_t &j, uint32_t m, c
     if (j == m) { ++cnt; j = fail[m - 1u]; }                   /* serial.c:203-206: overlapping matches count */
 }
 
-/* v_min3_u32: written as asm because hipcc re-associates min(a, min(b, c)) chains into extra v_min_u32 */
-__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-/* Candidate test for the 16 start offsets of a lane, VALU only: min over (dword ^ first), kept per group of
- * four offsets (g[q] covers offsets 4q..4q+3) so that the rare path only looks at the groups that hold a
- * candidate; 12 v_alignbyte + 16 v_xor + 4 v_min + 6 v_min3 and no scalar work. */
-template <bool MASKED>
-__device__ __forceinline__ uint32_t filter_min(const uint32_t (&w)[5], uint32_t first, uint32_t mask, uint32_t (&g)[4])
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t lo = w[q], hi = w[q + 1];
-        uint32_t x0 = lo ^ first;
-        uint32_t x1 = __builtin_amdgcn_alignbyte(hi, lo, 1) ^ first;
-        uint32_t x2 = __builtin_amdgcn_alignbyte(hi, lo, 2) ^ first;
-        uint32_t x3 = __builtin_amdgcn_alignbyte(hi, lo, 3) ^ first;
-        if (MASKED) { x0 &= mask; x1 &= mask; x2 &= mask; x3 &= mask; }
-        g[q] = min3u(min(x0, x1), x2, x3);
-    }
-    return min3u(min(g[0], g[1]), g[2], g[3]);      /* 0 iff some start offset of this lane shows the pattern's first bytes */
-}
-
 /* ballot of a lane predicate: the compare's SGPR pair itself, no VALU select */
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -118,29 +91,25 @@ __device__ __forceinline__ void flat_issue(u32x4 &dst, i32x4 rsrc, uint32_t vo, 
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
 }
 
-/* Per-launch constants of one pattern as the streaming kernels use them. */
+/* Per-launch constants of one pattern as the streaming kernels use them: its length and its first 16 bytes as
+ * four dwords, 0x00 beyond the pattern's end (the masked SAD skips a 0x00 reference byte, so patterns shorter than a
+ * dword, or ending inside one, need no mask registers and no kernel variant of their own). */
 struct PatConst {
-    uint32_t m, first, mask;
-    uint32_t pd[4], pm[4];          /* pattern bytes 4..19 and their byte masks (direct confirmation, m <= 20) */
+    uint32_t m;
+    uint32_t p[4];
 };
 
 __device__ __forceinline__ PatConst load_pat_const(const kmp_pattern_dev *gp)
 {
     PatConst pc;
-    pc.m = gp->m; pc.first = gp->first; pc.mask = gp->mask;
+    pc.m = gp->m;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const uint32_t lo = 4u * (uint32_t)(d + 1);
-        pc.pd[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d + 1];
-        pc.pm[d] = (pc.m >= lo + 4u) ? 0xFFFFFFFFu : (pc.m <= lo) ? 0u : ((1u << (8u * (pc.m - lo))) - 1u);
-    }
+    for (int d = 0; d < 4; ++d) pc.p[d] = reinterpret_cast<const uint32_t *>(gp->pat)[d];
     /* Take the scalar loads' results HERE.  Left alone the compiler postpones the s_waitcnt lgkmcnt(0) to the
      * first use of each constant, i.e. to several places inside the streaming loop, where such a wait also
      * covers the bitmap words the loop has just asked for (scalar loads return out of order: only lgkmcnt(0)
      * exists for them). */
-    asm volatile("" : "+s"(pc.m), "+s"(pc.first), "+s"(pc.mask));
-    asm volatile("" : "+s"(pc.pd[0]), "+s"(pc.pd[1]), "+s"(pc.pd[2]), "+s"(pc.pd[3]));
-    asm volatile("" : "+s"(pc.pm[0]), "+s"(pc.pm[1]), "+s"(pc.pm[2]), "+s"(pc.pm[3]));
+    asm volatile("" : "+s"(pc.m), "+s"(pc.p[0]), "+s"(pc.p[1]), "+s"(pc.p[2]), "+s"(pc.p[3]));
     return pc;
 }
 
@@ -179,39 +148,6 @@ __device__ __forceinline__ void emit_match(bool ok, uint64_t pkt, uint32_t offse
     emit_match_as<EMIT>(ok, pkt, offset, e.pattern, e);
 }
 
-/* KMP automaton for the streaming kernels: the lane scans the text from its own first byte; it
- * stops at a 0x00 (serial.c:191) or at the payload end; matches found all start inside the lane's
- * 16 bytes because at most 15 + m bytes are consumed. */
-template <bool EMIT>
-__device__ __forceinline__ void automaton_flat(uint4 cur, uint4 nxt, bool act, uint32_t p0, uint32_t L, uint32_t m,
-                                               const kmp_pattern_dev &sp, uint32_t &cnt, uint64_t pkt, const Emitter &em)
-{
-    uint32_t j = 0u;
-    const uint32_t nsteps = 15u + m;
-    uint32_t c0 = cur.x, c1 = cur.y, c2 = cur.z, c3 = cur.w;
-    uint32_t n0 = nxt.x, n1 = nxt.y, n2 = nxt.z, n3 = nxt.w;
-    uint32_t t0 = p0;
-    for (uint32_t done = 0u; done < nsteps; done += 16u) {
-        const uint32_t lim = min(16u, nsteps - done);
-#pragma unroll 1
-        for (uint32_t s = 0u; s < lim; ++s) {
-            const uint32_t w  = (s & 8u) ? ((s & 4u) ? c3 : c2) : ((s & 4u) ? c1 : c0);
-            const uint32_t ch = (w >> (8u * (s & 3u))) & 0xFFu;
-            act = act && (ch != 0u) && (t0 + s < L);
-            if (act) {
-                const uint32_t before = cnt;
-                kmp_step(ch, j, m, sp.pat, sp.fail, cnt);
-                emit_match<EMIT>(cnt != before, pkt, t0 + s + 1u - m, em);
-            }
-        }
-        t0 += 16u;
-        if (ballot64(act) == 0ull) break;
-        const uint32_t f0 = sgpr(n0), f1 = sgpr(n1), f2 = sgpr(n2), f3 = sgpr(n3);
-        c0 = wave_shl1(c0, f0); c1 = wave_shl1(c1, f1); c2 = wave_shl1(c2, f2); c3 = wave_shl1(c3, f3);
-        n0 = wave_shl1(n0, 0u); n1 = wave_shl1(n1, 0u); n2 = wave_shl1(n2, 0u); n3 = wave_shl1(n3, 0u);
-    }
-}
-
 /* Rare path, part 1: cut a lane's largest valid start index down by the strlen() rule -- no start
  * behind a 0x00 of the same packet (earlier lanes since the packet's start lane, or an earlier
  * chunk: dead_in), and none behind the first 0x00 of the lane's own 16 bytes. */
@@ -234,55 +170,188 @@ __device__ __forceinline__ int32_t nul_limit(int32_t maxi, const uint32_t (&w)[5
     return nul_before ? -1 : min(maxi, (int32_t)zi - 1);
 }
 
-/* Rare path, part 2: count (and optionally emit) the matches that start at index <= maxi of each
- * lane.  Patterns of <= 4 bytes are exact after the filter; 5..20 bytes with few candidate lanes are
- * compared dword-wise straight from registers (W = the lane's 16 bytes + the next 20 of the stream);
- * everything else runs the KMP automaton. */
-template <bool MASKED, bool EMIT>
-__device__ __forceinline__ void confirm_lanes(const uint32_t (&w)[5], const uint32_t (&g)[4], uint4 v, u32x4 bn, int32_t maxi, uint32_t p0, uint32_t L,
-                                              const PatConst &pc, const kmp_pattern_dev &sp, uint32_t &cnt, uint64_t pkt,
-                                              const Emitter &em)
+/* packed 16-bit helpers (VOP3P), written as asm so that the instruction selection is what the cost model assumes;
+ * the second operand may sit in an SGPR (constants) */
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+/* per half: max(0, k - b), k a wave-uniform constant */
+__device__ __forceinline__ uint32_t pk_rsub_sat_u16(uint32_t k, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "s"(k), "v"(b));
+    return r;
+}
+/* non-zero iff one of the two 16-bit halves of x is zero */
+__device__ __forceinline__ uint32_t zero_half_mask(uint32_t x) { return (x - 0x00010001u) & ~x & 0x80008000u; }
+
+/* v_mqsad_pk_u16_u8: four masked byte-SADs in one instruction.  Result k (bits [16k, 16k+16)) = acc_k + the sum over
+ * the reference's four bytes b of |text byte (k + b) - ref byte b|, a 0x00 reference byte being skipped; text = the 8
+ * bytes {lo, hi}.  So ONE instruction compares one pattern dword at four consecutive start offsets, alignment included,
+ * and accumulates: a start offset matches the pattern's bytes seen so far iff its sum is still 0.  Semantics and cost
+ * measured on MI355X (tools/sadtest.hip, profiles/r02_sadtest.txt): 7.3-8.2 ns per instruction per SIMD = 4
+ * three-operand VALU instructions, against 3 v_alignbyte + 4 v_xor + 4 v_or (filter) or + 4 v_sad_u8 (comparison) for
+ * the same four results. */
+__device__ __forceinline__ uint64_t mqsad(uint32_t lo, uint32_t hi, uint32_t ref, uint64_t acc)
+{
+    return __builtin_amdgcn_mqsad_pk_u16_u8(((uint64_t)hi << 32) | lo, ref, acc);
+}
+
+/* Candidate test for the 16 start offsets of a lane: S[q] = the four sums of the pattern's first dword (its first
+ * min(m, 4) bytes) against the start offsets 4q .. 4q+3; t[q] = their minimum per 16-bit half; the return value has a
+ * zero half iff some start offset of this lane shows the pattern's first bytes.  4 v_mqsad + 7 v_pk_min_u16.  The sums
+ * stay in registers: the rare path continues to accumulate the pattern's other dwords into them. */
+__device__ __forceinline__ uint32_t filter_sad(const uint32_t (&w)[5], uint32_t first, uint64_t (&S)[4], uint32_t (&t)[4])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        S[q] = mqsad(w[q], w[q + 1], first, 0ull);
+        t[q] = pk_min_u16((uint32_t)S[q], (uint32_t)(S[q] >> 32));
+    }
+    return pk_min_u16(pk_min_u16(t[0], t[1]), pk_min_u16(t[2], t[3]));
+}
+
+/* != 0 iff a 16-bit half of x is zero (sums stay below 2^15): the product of the halves, one SDWA instruction */
+__device__ __forceinline__ uint32_t halves_product(uint32_t x)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+/* Rare path, part 2: count (and optionally emit) the matches that start at index <= maxi of each lane.
+ *
+ * Every start offset of every lane is compared in full, with no per-candidate branching, so that text made of
+ * candidates (one letter, two letters, a pattern that is everywhere) costs a small multiple of the filter instead of
+ * a byte-serial automaton per lane:
+ *   S[q]   the filter's sums (first pattern dword) for the start offsets 4q .. 4q+3;
+ *   block 0 adds the pattern dwords 1..3 (bytes 4..15) against the lane's own 16 bytes and the 16 that follow (DPP
+ *          wave_shl:1, lane 63 continuing in the next chunk); block k >= 1 (patterns of more than 16 bytes) compares
+ *          the bytes 16k .. 16k+15 against the data of lane + k and lane + k + 1.  Zero pattern bytes past the
+ *          pattern's end are skipped by the masked SAD.  Between blocks the wavefront leaves as soon as no lane has a
+ *          zero sum left (false candidates of a long pattern die in block 0);
+ *   a start offset counts iff its sum is still 0 after the last block and its index is <= maxi.
+ * Only the groups of four offsets in which some lane passed the filter are worked on: with sparse candidates that is
+ * one group, with dense ones all four.  ND = pattern dwords compared in block 0 (1: the filter was exact, 4: all).
+ * barred (wave-uniform): some candidate lane may not count all of its 16 start offsets (payload end or a 0x00 nearby):
+ * the sums of the offsets above maxi are raised first (per half: max(sum, max(0, index - maxi))). */
+template <bool EMIT>
+__device__ __forceinline__ uint32_t tally_group(int q, uint64_t Sq, bool barred, uint32_t nv2, uint32_t found, uint32_t p0, uint32_t &cnt, uint64_t pkt,
+                                                const Emitter &em)
+{
+    uint32_t lo = (uint32_t)Sq, hi = (uint32_t)(Sq >> 32);
+    if (barred) {
+        asm volatile("" ::: "memory");
+        lo = pk_max_u16(lo, pk_rsub_sat_u16((uint32_t)(4 * q + 1) | ((uint32_t)(4 * q + 2) << 16), nv2));
+        hi = pk_max_u16(hi, pk_rsub_sat_u16((uint32_t)(4 * q + 3) | ((uint32_t)(4 * q + 4) << 16), nv2));
+    }
+    if (!EMIT) return pk_add_u16(found, pk_add_u16(pk_rsub_sat_u16(0x00010001u, lo), pk_rsub_sat_u16(0x00010001u, hi)));     /* 1 - min(x, 1) per half */
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const bool ok = (((a < 2 ? lo : hi) >> (16 * (a & 1))) & 0xFFFFu) == 0u;
+        cnt += ok ? 1u : 0u;
+        emit_match<EMIT>(ok, pkt, p0 + (uint32_t)(4 * q + a), em);
+    }
+    return found;
+}
+
+template <int ND, bool EMIT>
+__device__ __forceinline__ void confirm_block0(uint64_t (&S)[4], const uint32_t (&t)[4], const uint32_t (&c)[8], bool barred, uint32_t nv2, uint32_t p0,
+                                               const PatConst &pc, bool more, uint32_t &cnt, uint64_t pkt, const Emitter &em, bool (&on)[4])
+{
+    uint32_t found = 0u;                                            /* packed: matches at the even / odd offsets */
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        on[q] = ballot64(halves_product(t[q]) == 0u) != 0ull;
+        if (!on[q]) continue;
+        asm volatile("" ::: "memory");                              /* keep the wave-uniform branch: no select-both-ways */
+        if (ND > 1) {
+            /* all three further dwords, whatever the length: a dword past the pattern's end is 0x00000000 and adds
+             * nothing (two idle instructions per group for patterns of 5..8 bytes, against a branch per dword and group) */
+            S[q] = mqsad(c[q + 1], c[q + 2], pc.p[1], S[q]);
+            S[q] = mqsad(c[q + 2], c[q + 3], pc.p[2], S[q]);
+            S[q] = mqsad(c[q + 3], c[q + 4], pc.p[3], S[q]);
+        }
+        if (more) continue;                                         /* a pattern of more than 16 bytes: not decided yet */
+        found = tally_group<EMIT>(q, S[q], barred, nv2, found, p0, cnt, pkt, em);
+    }
+    if (!EMIT) cnt += (found & 0xFFFFu) + (found >> 16);
+}
+
+/* fz != 0 marks the lanes with a candidate; maxi < 0 those that may count nothing */
+template <bool EMIT>
+__device__ __forceinline__ void confirm_sad(uint64_t (&S)[4], const uint32_t (&t)[4], const uint32_t (&w)[5], uint4 v, u32x4 bn, uint32_t fz, int32_t maxi,
+                                            uint32_t p0, const PatConst &pc, const kmp_pattern_dev *gp, uint32_t &cnt, uint64_t pkt,
+                                            const Emitter &em)
 {
     const uint32_t m = pc.m;
-    const uint64_t ba = ballot64(maxi >= 0);
-    if (m <= 4u) {
+    /* the common case of the rare path: every candidate lane may count all 16 of its start offsets */
+    const bool barred = ballot64(maxi < 15 && fz != 0u) != 0ull;
+    uint32_t nv2 = 0u;
+    if (barred) {
+        if (ballot64(maxi >= 0) == 0ull) return;
+        const uint32_t nv = (uint32_t)min(max(maxi + 1, 0), 16);
+        nv2 = nv | (nv << 16);
+    }
+    uint32_t c[8] = {w[0], w[1], w[2], w[3], w[4], 0u, 0u, 0u};
+    bool on[4];
+    if (m <= 4u) { confirm_block0<1, EMIT>(S, t, c, barred, nv2, p0, pc, false, cnt, pkt, em, on); return; }
+    /* the 16 bytes that follow the lane's own (the first dword of them is w[4]) */
+    c[5] = wave_shl1(v.y, sgpr(bn.y)); c[6] = wave_shl1(v.z, sgpr(bn.z)); c[7] = wave_shl1(v.w, sgpr(bn.w));
+    const bool more = m > 16u;
+    confirm_block0<4, EMIT>(S, t, c, barred, nv2, p0, pc, more, cnt, pkt, em, on);
+    if (!more) return;
+
+    for (uint32_t k = 1u; 16u * k < m; ++k) {
+        /* does any lane still have a start offset whose sum is 0? */
+        uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (on[q]) mn = pk_min_u16(mn, pk_min_u16((uint32_t)S[q], (uint32_t)(S[q] >> 32)));
+        if (ballot64(halves_product(mn) == 0u) == 0ull) return;
+        /* 16 bytes further on; lane 63 continues with lane k of the next chunk */
+        const uint4 pk = reinterpret_cast<const uint4 *>(gp->pat)[k];
+        const uint32_t left = m - 16u * k;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = c[j + 4];
+        c[4] = wave_shl1(c[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, (int)k));
+        c[5] = wave_shl1(c[5], (uint32_t)__builtin_amdgcn_readlane((int)bn.y, (int)k));
+        c[6] = wave_shl1(c[6], (uint32_t)__builtin_amdgcn_readlane((int)bn.z, (int)k));
+        c[7] = wave_shl1(c[7], (uint32_t)__builtin_amdgcn_readlane((int)bn.w, (int)k));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (ballot64(g[q] == 0u) == 0ull) continue;           /* no lane has a candidate among offsets 4q..4q+3 */
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
-                const bool ok = is_cand<MASKED>(d0, pc.first, pc.mask) && (4 * q + a) <= maxi;
-                cnt += ok ? 1u : 0u;
-                emit_match<EMIT>(ok, pkt, p0 + (uint32_t)(4 * q + a), em);
-            }
-        }
-    } else if (ba != 0ull) {
-        if (m <= 20u && __builtin_popcountll(ba) <= 16) {
-            const uint32_t W[10] = {w[0], w[1], w[2], w[3], w[4], wave_shl1(v.y, sgpr(bn.y)), wave_shl1(v.z, sgpr(bn.z)),
-                                    wave_shl1(v.w, sgpr(bn.w)), wave_shl1(w[4], (uint32_t)__builtin_amdgcn_readlane((int)bn.x, 1)), 0u};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (ballot64(g[q] == 0u) == 0ull) continue;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(W[q + 1], W[q], a) : W[q];
-                    bool ok = (d0 == pc.first) && (4 * q + a) <= maxi;
-                    if (ballot64(ok) != 0ull) {
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const uint32_t t = a ? __builtin_amdgcn_alignbyte(W[q + d + 2], W[q + d + 1], a) : W[q + d + 1];
-                            ok = ok && (((t ^ pc.pd[d]) & pc.pm[d]) == 0u);
-                        }
-                        cnt += ok ? 1u : 0u;
-                        emit_match<EMIT>(ok, pkt, p0 + (uint32_t)(4 * q + a), em);
-                    }
-                }
-            }
-        } else {
-            automaton_flat<EMIT>(v, make_uint4(bn.x, bn.y, bn.z, bn.w), maxi >= 0, p0, L, m, sp, cnt, pkt, em);
+            if (!on[q]) continue;
+            asm volatile("" ::: "memory");
+            S[q] = mqsad(c[q], c[q + 1], pk.x, S[q]);
+            if (left > 4u)  { asm volatile("" ::: "memory"); S[q] = mqsad(c[q + 1], c[q + 2], pk.y, S[q]); }
+            if (left > 8u)  { asm volatile("" ::: "memory"); S[q] = mqsad(c[q + 2], c[q + 3], pk.z, S[q]); }
+            if (left > 12u) { asm volatile("" ::: "memory"); S[q] = mqsad(c[q + 3], c[q + 4], pk.w, S[q]); }
         }
     }
+    /* matches = the sums that are still 0, at start offsets 0 .. maxi */
+    uint32_t found = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!on[q]) continue;
+        asm volatile("" ::: "memory");
+        found = tally_group<EMIT>(q, S[q], barred, nv2, found, p0, cnt, pkt, em);
+    }
+    if (!EMIT) cnt += (found & 0xFFFFu) + (found >> 16);
 }
 
 

@@ -54,13 +54,12 @@ namespace {
  * ============================================================================================== */
 
 
-template <int DEPTH, bool MASKED, bool NT, bool EMIT = false>
+template <int DEPTH, bool NT, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
                      uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
                      const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
 {
-    __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
 
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
@@ -84,12 +83,8 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
 
     const uint32_t pid = pat_ids[blockIdx.y];
     const kmp_pattern_dev *gp = patterns + pid;
-    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
-        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
-    __syncthreads();
-
     const PatConst pc = load_pat_const(gp);
-    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
+    const uint32_t m = pc.m;
     if (EMIT) em.pattern = pid;
 
     uint32_t cnt = 0u;
@@ -108,11 +103,12 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
-                    uint32_t g[4];
-                    const uint32_t fm = filter_min<MASKED>(w, first, mask, g);
+                    uint64_t S[4];
+                    uint32_t t[4];
+                    const uint32_t fz = zero_half_mask(filter_sad(w, pc.p[0], S, t));      /* != 0 iff the lane has a candidate */
                     const uint64_t zl = ballot64(zm != 0u);                   /* lanes holding a 0x00           */
                     const uint64_t st = ballot64(p0 == 0u);                   /* lanes where a packet starts    */
-                    const uint64_t cl = ballot64(fm == 0u);                   /* lanes with a candidate         */
+                    const uint64_t cl = ballot64(fz != 0u);                   /* lanes with a candidate         */
                     const bool dead_in = dead;
                     /* carry for the next chunk: is there a 0x00 at or after the last packet start of this chunk? */
                     if (zl == 0ull) { if (st != 0ull) dead = false; }
@@ -122,10 +118,10 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                         /* rare path.  maxi = largest start index (0..15) of this lane that still counts:
                          * window inside the payload, no 0x00 before it, lane has a candidate at all. */
                         int32_t maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
-                        if (fm != 0u) maxi = -1;
+                        if (fz == 0u) maxi = -1;
                         if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
                         const uint64_t pkt = EMIT ? (k0 + (uint64_t)((cb + vo0 - p0) / stride)) : 0ull;
-                        confirm_lanes<MASKED, EMIT>(w, g, v, bn, maxi, p0, L, pc, s_pat, cnt, pkt, em);
+                        confirm_sad<EMIT>(S, t, w, v, bn, fz, maxi, p0, pc, gp, cnt, pkt, em);
                     }
                     /* this lane's position inside its packet, one chunk further */
                     p0 += step_mod;
@@ -195,7 +191,7 @@ kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict
     plan[w].off = (lo < n) ? pkt_off[lo] : end;
 }
 
-template <int DEPTH, bool MASKED, bool NT, bool EMIT = false>
+template <int DEPTH, bool NT, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
                        const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,
@@ -203,7 +199,6 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                        const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em,
                        uint32_t pad_clean)
 {
-    __shared__ kmp_pattern_dev s_pat;
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
 
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
@@ -229,12 +224,8 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
 
     const uint32_t pid = pat_ids[blockIdx.y];
     const kmp_pattern_dev *gp = patterns + pid;
-    if (threadIdx.x < sizeof(kmp_pattern_dev) / 4u)
-        reinterpret_cast<uint32_t *>(&s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(gp)[threadIdx.x];
-    __syncthreads();
-
     const PatConst pc = load_pat_const(gp);
-    const uint32_t m = pc.m, first = pc.first, mask = pc.mask;
+    const uint32_t m = pc.m;
     if (EMIT) em.pattern = pid;
 
     uint32_t cnt = 0u;
@@ -283,10 +274,11 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
-                    uint32_t g[4];
-                    const uint32_t fm = filter_min<MASKED>(w, first, mask, g);
+                    uint64_t S[4];
+                    uint32_t t[4];
+                    const uint32_t fz = zero_half_mask(filter_sad(w, pc.p[0], S, t));      /* != 0 iff the lane has a candidate */
                     const uint64_t zl = ballot64(zm != 0u);
-                    const uint64_t cl = ballot64(fm == 0u);
+                    const uint64_t cl = ballot64(fz != 0u);
                     const bool dead_in = dead;
                     if (zl == 0ull) { if (st != 0ull) dead = false; }
                     else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
@@ -301,7 +293,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                              * the payload" = "it lies inside the slot and holds no 0x00": the distance to the next
                              * packet start, read off the bitmap, replaces the payload's offset and length -- no
                              * gather from the index, which costs a memory round trip per candidate chunk. */
-                            if (fm == 0u) {
+                            if (fz != 0u) {
                                 const uint64_t above = (st >> 1) >> lane;               /* starts at the lanes above own */
                                 uint32_t d = 4096u;                                     /* 16-byte groups up to the next start */
                                 if (above != 0ull) d = (uint32_t)__builtin_ctzll(above) + 1u;
@@ -314,7 +306,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                                 L = d * KMP_LANE_BYTES;                                 /* bytes from the lane's first to the slot's end */
                                 maxi = (int32_t)L - (int32_t)m;
                             }
-                        } else if (fm == 0u) {
+                        } else if (fz != 0u) {
                             const uint64_t le = (2ull << lane) - 1ull;                  /* lanes <= own (lane 63: all ones) */
                             kl = kbase + (uint64_t)__builtin_popcountll(st & le);
                             const uint64_t po = pkt_off[kl];
@@ -323,7 +315,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                             maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
                         }
                         if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
-                        confirm_lanes<MASKED, EMIT>(w, g, v, bn, maxi, p0, L, pc, s_pat, cnt, kl, em);
+                        confirm_sad<EMIT>(S, t, w, v, bn, fz, maxi, p0, pc, gp, cnt, kl, em);
                         /* leave nothing of the rare path's LDS/scalar reads "possibly in flight": merged into the
                          * common path that state costs an s_waitcnt lgkmcnt(0) per chunk, which would also wait
                          * for the bitmap words just asked for */
@@ -367,37 +359,25 @@ Emitter emitter_of(const kmp_scan_args &a)
     return e;
 }
 
-template <int DEPTH, bool MASKED>
+template <int DEPTH>
 hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
 {
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
     const Emitter em = emitter_of(a);
 #define KMP_FLAT_ARGS a.arena, a.n_pkts, a.uniform_stride, a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials, em
     if (a.emit_out)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_FLAT_ARGS);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<4, true, true>), grid, block, 0, st, KMP_FLAT_ARGS);
     else if (a.nontemporal)
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_FLAT_ARGS);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, true>), grid, block, 0, st, KMP_FLAT_ARGS);
     else
-        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, MASKED, false>), grid, block, 0, st, KMP_FLAT_ARGS);
+        hipLaunchKernelGGL((kmp_scan_flat_kernel<DEPTH, false>), grid, block, 0, st, KMP_FLAT_ARGS);
 #undef KMP_FLAT_ARGS
     return hipGetLastError();
-}
-template <bool MASKED>
-hipError_t launch_flat_d(const kmp_scan_args &a, hipStream_t st)
-{
-    switch (a.depth) {
-    case 2: return launch_flat_t<2, MASKED>(a, st);
-    case 3: return launch_flat_t<3, MASKED>(a, st);
-    case 5: return launch_flat_t<5, MASKED>(a, st);
-    case 6: return launch_flat_t<6, MASKED>(a, st);
-    case 8: return launch_flat_t<8, MASKED>(a, st);
-    default: return launch_flat_t<4, MASKED>(a, st);
-    }
 }
 }  // namespace
 
 namespace {
-template <int DEPTH, bool MASKED>
+template <int DEPTH>
 hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
 {
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
@@ -405,11 +385,11 @@ hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
     const Emitter em = emitter_of(a);
 #define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, em, (a.pad_clean ? 1u : 0u)
     if (a.emit_out)
-        hipLaunchKernelGGL((kmp_scan_packed_kernel<4, MASKED, true, true>), grid, block, 0, st, KMP_PACKED_ARGS);
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<4, true, true>), grid, block, 0, st, KMP_PACKED_ARGS);
     else if (a.nontemporal)
-        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, true>), grid, block, 0, st, KMP_PACKED_ARGS);
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, true>), grid, block, 0, st, KMP_PACKED_ARGS);
     else
-        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, MASKED, false>), grid, block, 0, st, KMP_PACKED_ARGS);
+        hipLaunchKernelGGL((kmp_scan_packed_kernel<DEPTH, false>), grid, block, 0, st, KMP_PACKED_ARGS);
 #undef KMP_PACKED_ARGS
     return hipGetLastError();
 }
@@ -420,9 +400,9 @@ hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st)
 {
     if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
     switch (a.depth) {          /* 0 = auto: 3 chunks in flight measured best here (profiles/r01_packed_tuning.txt) */
-    case 4: case 5: return a.masked ? launch_packed_t<4, true>(a, st) : launch_packed_t<4, false>(a, st);
-    case 6: case 8: return a.masked ? launch_packed_t<6, true>(a, st) : launch_packed_t<6, false>(a, st);
-    default: return a.masked ? launch_packed_t<3, true>(a, st) : launch_packed_t<3, false>(a, st);
+    case 4: case 5: return launch_packed_t<4>(a, st);
+    case 6: case 8: return launch_packed_t<6>(a, st);
+    default: return launch_packed_t<3>(a, st);
     }
 }
 
@@ -449,6 +429,13 @@ hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uin
 hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st)
 {
     if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
-    return a.masked ? launch_flat_d<true>(a, st) : launch_flat_d<false>(a, st);
+    switch (a.depth) {
+    case 2: return launch_flat_t<2>(a, st);
+    case 3: return launch_flat_t<3>(a, st);
+    case 5: return launch_flat_t<5>(a, st);
+    case 6: return launch_flat_t<6>(a, st);
+    case 8: return launch_flat_t<8>(a, st);
+    default: return launch_flat_t<4>(a, st);
+    }
 }
 

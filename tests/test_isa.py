@@ -17,7 +17,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 def _isa(src, tmp):
     out = os.path.join(tmp, os.path.basename(src) + ".s")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}", "-S", "--cuda-device-only",
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=1048576",      # as csrc/Makefile
+                        f"-I{ROOT}/include", f"-I{CSRC}", "-S", "--cuda-device-only",
                         "-o", out, os.path.join(CSRC, src)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     text = open(out).read()
@@ -51,7 +52,7 @@ def _issues(body):
 
 
 def test_no_spills_no_dynamic_register_indexing(stream, multi):
-    assert len(stream) >= 30 and len(multi) >= 6
+    assert len(stream) >= 20 and len(multi) >= 6
     for name, k in list(stream.items()) + list(multi.items()):
         assert k["scratch"] == 0, name
         assert "movrel" not in k["body"], name                     # a ring slot reached through a run-time index
@@ -65,9 +66,17 @@ def test_flat_kernel_ring_is_unrolled(stream, depth):
         drain = (depth + 1) // 2 if depth == 2 else 0               # the final drain waits for vmcnt(0) as well
         assert _ring_waits(k["body"], depth - 2) == depth + drain, name     # one wait per slot of the steady-state loop
         assert _issues(k["body"]) == 2 * depth, name                # prologue + one re-issue per slot
-        # the default (4 chunks in flight, pattern of 4+ bytes): <= 64 VGPRs, eight wavefronts per SIMD; deeper rings and the
-        # masked (< 4 bytes) variants carry more state; 4 blocks/CU need 4 wavefronts per SIMD
-        assert k["occupancy"] >= (8 if depth == 4 and "ILi4ELb0E" in name else 5), (name, k["vgprs"])
+        # the persistent grid of the flat kernel is 4 blocks per CU = 4 wavefronts per SIMD; keep a margin
+        assert k["occupancy"] >= 5, (name, k["vgprs"])
+
+
+def test_emit_variants_are_unrolled_too(stream):
+    """kmpgpu_scan_offsets: the EMIT instantiations (4 chunks in flight) carry a large rare path; their rings must be unrolled all the same."""
+    ks = {n: k for n, k in stream.items() if ("kmp_scan_flat_kernelILi4E" in n or "kmp_scan_packed_kernelILi4E" in n) and "ELb1EEEv" in n}
+    assert len(ks) == 2, list(stream)
+    for name, k in ks.items():
+        assert _ring_waits(k["body"], 2) == 4, name
+        assert _issues(k["body"]) == 8, name
 
 
 @pytest.mark.parametrize("depth", [3, 4, 6])
@@ -77,7 +86,7 @@ def test_packed_kernel_ring_is_unrolled(stream, depth):
     for name, k in ks.items():
         assert _ring_waits(k["body"], depth - 2) == depth, name
         assert _issues(k["body"]) == 2 * depth, name
-        assert k["occupancy"] >= (8 if depth == 3 and "ILi3ELb0E" in name else 5), (name, k["vgprs"])       # 3 in flight is the default here
+        assert k["occupancy"] >= (7 if depth == 3 else 5), (name, k["vgprs"])       # 3 in flight is the default here; 6 blocks per CU need 6
 
 
 def test_fused_kernel_ring_is_unrolled(multi):
