@@ -49,6 +49,7 @@ typedef struct kmpgpu_timing {
     double   d2h_ms;          /* counts download                                           */
     uint32_t launches;        /* scan-kernel launches in the last scan                     */
     uint32_t grid_blocks;     /* blocks per launch (x dimension)                           */
+    uint64_t h2d_bytes;       /* bytes the last kmpgpu_load_arena / kmpgpu_load_frames copied to the device */
 } kmpgpu_timing;
 
 /* One reported match (kmpgpu_scan_offsets).  Not in the reference, which prints counts only
@@ -130,7 +131,12 @@ int  kmpgpu_load_frames(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t fil
                         const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads);
 
 /* Same, for an arena already resident in device memory (borrowed; same contract, checked by a
- * device-side pass; an arena that is not packed is copied unless KMPGPU_OPT_REPACK is 0).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*. */
+ * device-side pass; an arena that is not packed is copied unless KMPGPU_OPT_REPACK is 0).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*.
+ * IMMUTABILITY: the call derives state from the buffers -- packet-start bitmap, wavefront plan, uniform / packed
+ * flags, the slot-padding check -- so arena AND index must stay unchanged for as long as they are attached.  A
+ * device-resident batch ring that refills a buffer in place calls kmpgpu_attach_arena again after every refill (the
+ * derived state is rebuilt by a few small kernels, no copy of the arena); scanning a rewritten buffer without it
+ * counts against the OLD packet boundaries. */
 int  kmpgpu_attach_arena(kmpgpu_ctx *ctx, const void *d_arena, uint64_t arena_bytes,
                          const void *d_pkt_off, const void *d_pkt_len, uint64_t n_pkts);
 
@@ -147,11 +153,39 @@ int  kmpgpu_scan_enqueue(kmpgpu_ctx *ctx, void *d_counts_out);
 void *kmpgpu_counts_device(kmpgpu_ctx *ctx);
 /* Zero the context's own counts buffer (asynchronous, on the context's stream). */
 int  kmpgpu_counts_reset(kmpgpu_ctx *ctx);
+/* dst's counters += src's (both contexts on the same device, same patterns): the merge of contexts that share a GPU,
+ * e.g. the two double-buffering contexts of a streamed capture (openmp_task.c:172-175).  Waits for src's stream, then
+ * enqueues the addition on dst's. */
+int  kmpgpu_counts_add(kmpgpu_ctx *dst, kmpgpu_ctx *src);
 /* Timing of the context's last kmpgpu_load_arena / kmpgpu_load_frames / kmpgpu_scan. */
 int  kmpgpu_last_timing(kmpgpu_ctx *ctx, kmpgpu_timing *t);
 /* Wait for the context's stream and copy its own counts buffer to the host (uint64_t[n_pat]). */
 int  kmpgpu_counts_read(kmpgpu_ctx *ctx, uint64_t *counts_out);
 int  kmpgpu_sync(kmpgpu_ctx *ctx);
+
+/* ---- the count reduce over GPUs: replaces MPI_Reduce(local_string_count, string_count, n, MPI_INT, MPI_SUM, 0, comm),
+ * mpi_dumping.c:202 (and the scatter's rank/size bookkeeping, mpi_dumping.c:29-31) -- RCCL over xGMI.  librccl.so is
+ * opened on the first call (no link-time dependency: single-GPU callers never load it).
+ *
+ * One rank per context, every context on its own device.
+ *   kmpgpu_comm_init       all ranks live in THIS process (ncclCommInitAll): ctx[0..n_ctx) on n_ctx distinct devices;
+ *   kmpgpu_comm_init_rank  one process per GPU (as mpirun starts mpi_dumping): rank `rank` of `n_ranks`, `unique_id`
+ *                          (KMPGPU_COMM_ID_BYTES bytes) made once by kmpgpu_comm_unique_id and handed to every
+ *                          rank by the launcher (file, environment, socket ...);
+ *   kmpgpu_comm_allreduce_counts   enqueue ncclAllReduce(ncclUint64, ncclSum) in place over every local context's
+ *                          counts buffer (kmpgpu_counts_device), on that context's stream, i.e. after the passes
+ *                          enqueued so far (kmpgpu_scan_enqueue(ctx, NULL)); no host synchronisation: read the totals
+ *                          with kmpgpu_counts_read afterwards (every rank holds them, like MPI_Allreduce).
+ * All contexts of a communicator must hold the same number of patterns. */
+#define KMPGPU_COMM_ID_BYTES 128
+typedef struct kmpgpu_comm kmpgpu_comm;
+int  kmpgpu_comm_init(kmpgpu_comm **comm, kmpgpu_ctx *const *ctx, int n_ctx);
+int  kmpgpu_comm_unique_id(void *id_out);
+int  kmpgpu_comm_init_rank(kmpgpu_comm **comm, kmpgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
+int  kmpgpu_comm_allreduce_counts(kmpgpu_comm *comm);
+void kmpgpu_comm_destroy(kmpgpu_comm *comm);
+/* The device a context was created on. */
+int  kmpgpu_device_of(kmpgpu_ctx *ctx);
 
 /* Per-launch durations of the scan kernel, measured with HIP events on the launch stream.
  * begin(): start recording up to max_launches launches; end(): synchronise, write the

@@ -19,4 +19,4 @@ from .host import (  # noqa: F401
     synth_fill_host,
     write_udp_pcap,
 )
-from .matcher import GpuMatcher, count_matches, device_count  # noqa: F401
+from .matcher import GpuComm, GpuMatcher, count_matches, device_count  # noqa: F401

@@ -76,7 +76,7 @@ class Frames(C.Structure):
 class Timing(C.Structure):
     """kmpgpu_timing (include/kmpgpu.h)."""
     _fields_ = [("h2d_ms", C.c_double), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("launches", C.c_uint32), ("grid_blocks", C.c_uint32)]
+                ("launches", C.c_uint32), ("grid_blocks", C.c_uint32), ("h2d_bytes", C.c_uint64)]
 
 
 class Match(C.Structure):
@@ -130,6 +130,7 @@ GPU_API = {
     "kmpgpu_scan_enqueue": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kmpgpu_counts_device": (C.c_void_p, [C.c_void_p]),
     "kmpgpu_counts_reset": (C.c_int, [C.c_void_p]),
+    "kmpgpu_counts_add": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kmpgpu_last_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "kmpgpu_counts_read": (C.c_int, [C.c_void_p, u64p]),
     "kmpgpu_sync": (C.c_int, [C.c_void_p]),
@@ -140,6 +141,12 @@ GPU_API = {
     "kmpgpu_fixed_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
     "kmpgpu_arena_info": (C.c_int, [C.c_void_p, u64p, u64p]),
     "kmpgpu_effective_bytes": (C.c_int, [C.c_void_p, u64p]),
+    "kmpgpu_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]),
+    "kmpgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "kmpgpu_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "kmpgpu_comm_allreduce_counts": (C.c_int, [C.c_void_p]),
+    "kmpgpu_comm_destroy": (None, [C.c_void_p]),
+    "kmpgpu_device_of": (C.c_int, [C.c_void_p]),
 }
 
 

@@ -72,6 +72,56 @@ static void *warm_gpu(void *arg)
     return NULL;
 }
 
+/* One GPU shard: a contiguous range of the payloads (or, with KMPGPU_DEVICE_EXTRACT=1, of the frames). */
+typedef struct shard_job {
+    int device, tcp, threaded, rc;
+    uint64_t lo, cnt;                       /* first unit and number of units of this shard */
+    const kmp_arena *arena;
+    const kmp_frames *frames;               /* non-NULL: extraction on the device */
+    const uint8_t *const *pp;
+    const kmp_patterns *pats;
+    kmpgpu_ctx *ctx;
+    kmpgpu_timing t;
+    uint64_t n_payloads, payload_bytes;
+    uint64_t *reb, *own;
+    const char *what;
+    char err[512];
+    pthread_t thread;
+} shard_job;
+
+static void *shard_fail(shard_job *j, const char *what)
+{
+    j->rc = 1; j->what = what;
+    snprintf(j->err, sizeof j->err, "%s", kmpgpu_last_error());            /* the error text is per thread */
+    return NULL;
+}
+
+static void *shard_load(void *arg)
+{
+    shard_job *j = (shard_job *)arg;
+    if (kmpgpu_init(&j->ctx, j->device)) return shard_fail(j, "kmpgpu_init");
+    if (kmpgpu_set_patterns(j->ctx, j->pp, j->pats->len, j->pats->n)) return shard_fail(j, "kmpgpu_set_patterns");
+    if (j->frames) {
+        /* only the bytes this shard's frames span are uploaded (kmpgpu_load_frames) */
+        if (kmpgpu_load_frames(j->ctx, j->frames->bytes, j->frames->nbytes, j->frames->off + j->lo, j->frames->caplen + j->lo, j->cnt, j->tcp,
+                               &j->n_payloads))
+            return shard_fail(j, "kmpgpu_load_frames");
+        kmpgpu_arena_info(j->ctx, NULL, &j->payload_bytes);
+    } else {
+        const kmp_arena *a = j->arena;
+        const uint64_t hi = j->lo + j->cnt;
+        const uint64_t b0 = a->off[j->lo];
+        const uint64_t b1 = (hi < a->n_pkts) ? a->off[hi] : a->nbytes;
+        j->reb = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)j->cnt);
+        if (!j->reb) { j->rc = 1; j->what = "malloc"; snprintf(j->err, sizeof j->err, "out of memory"); return NULL; }
+        for (uint64_t k = 0; k < j->cnt; k++) j->reb[k] = a->off[j->lo + k] - b0;
+        /* slots are contiguous and at least 16 bytes each, so [b0, b1) holds the whole shard */
+        if (kmpgpu_load_arena(j->ctx, a->bytes + b0, b1 - b0, j->reb, a->len + j->lo, j->cnt)) return shard_fail(j, "kmpgpu_load_arena");
+    }
+    if (kmpgpu_last_timing(j->ctx, &j->t)) return shard_fail(j, "kmpgpu_last_timing");
+    return NULL;
+}
+
 int main(int argc, char *argv[])
 {
     int proto = KMP_PROTO_UDP;                                              /* serial.c:31 */
@@ -160,89 +210,98 @@ int main(int argc, char *argv[])
      * one extra pass over the arena, so it is opt-in and the "Elapsed time" line of a plain run stays comparable */
     const char *stats_env = getenv("KMPGPU_STATS");
     const int want_stats = stats_env && stats_env[0] && stats_env[0] != '0';
-    uint64_t eff_bytes = 0;
-    if (pats.n && device_extract && frames.n) {
-        /* frames split like mpi_dumping.c:149-157; every shard extracts and counts its own frames */
-        if ((uint64_t)shards > frames.n) shards = (int)frames.n;
+    uint64_t eff_bytes = 0, h2d_bytes = 0;
+    int reduce_rccl = 0;
+    const uint64_t units = device_extract ? frames.n : arena.n_pkts;       /* what is split over the shards */
+    if (pats.n && units) {
+        /* Shards: contiguous ranges, N/P each, the remainder to shard 0 (mpi_dumping.c:149-157); shard r on device
+         * r % ndev.  Every shard is brought up by its own host thread -- context, patterns, upload (and extraction) --
+         * so that the uploads of the shards run side by side, one PCIe link each (MPI_Scatterv, mpi_dumping.c:161). */
+        if ((uint64_t)shards > units) shards = (int)units;
+        shard_job *job = (shard_job *)calloc((size_t)shards, sizeof *job);
         uint64_t lo = 0;
         for (int r = 0; r < shards; r++) {
-            const uint64_t cnt = frames.n / (uint64_t)shards + (r == 0 ? frames.n % (uint64_t)shards : 0);
-            kmpgpu_ctx *ctx;
-            kmpgpu_timing t;
-            uint64_t np = 0;
-            if (kmpgpu_init(&ctx, r % ndev)) die_gpu("kmpgpu_init");
-            if (kmpgpu_set_patterns(ctx, pp, pats.len, pats.n)) die_gpu("kmpgpu_set_patterns");
-            if (kmpgpu_load_frames(ctx, frames.bytes, frames.nbytes, frames.off + lo, frames.caplen + lo, cnt, proto == KMP_PROTO_TCP, &np))
-                die_gpu("kmpgpu_load_frames");
-            if (kmpgpu_scan(ctx, part, &t)) die_gpu("kmpgpu_scan");
-            uint64_t pb = 0;
-            kmpgpu_arena_info(ctx, NULL, &pb);
-            arena.n_pkts += np; arena.payload_bytes += pb;
-            for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];
-            if (t.kernel_ms > kernel_ms) kernel_ms = t.kernel_ms;
-            h2d_ms += t.h2d_ms;
-            if (want_stats) { uint64_t e = 0; if (kmpgpu_effective_bytes(ctx, &e)) die_gpu("kmpgpu_effective_bytes"); eff_bytes += e; }
-            kmpgpu_destroy(ctx);
+            const uint64_t cnt = units / (uint64_t)shards + (r == 0 ? units % (uint64_t)shards : 0);
+            job[r].device = r % ndev; job[r].lo = lo; job[r].cnt = cnt;
+            job[r].arena = &arena; job[r].frames = device_extract ? &frames : NULL; job[r].tcp = proto == KMP_PROTO_TCP;
+            job[r].pp = pp; job[r].pats = &pats;
             lo += cnt;
         }
-        arena.n_frames = frames.n;
-    } else if (pats.n && arena.n_pkts) {
-        if ((uint64_t)shards > arena.n_pkts) shards = (int)arena.n_pkts;
-        kmpgpu_ctx **ctx = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *ctx);
-        uint64_t *reb = (uint64_t *)malloc(sizeof(uint64_t) * arena.n_pkts);
-        uint64_t lo = 0;
+        for (int r = 1; r < shards; r++)
+            if (pthread_create(&job[r].thread, NULL, shard_load, &job[r]) != 0) { job[r].threaded = 0; shard_load(&job[r]); } else job[r].threaded = 1;
+        shard_load(&job[0]);
+        for (int r = 1; r < shards; r++) if (job[r].threaded) pthread_join(job[r].thread, NULL);
         for (int r = 0; r < shards; r++) {
-            uint64_t cnt = arena.n_pkts / (uint64_t)shards + (r == 0 ? arena.n_pkts % (uint64_t)shards : 0);   /* mpi_dumping.c:149-152 */
-            const uint64_t hi = lo + cnt;
-            const uint64_t b0 = arena.off[lo];
-            const uint64_t b1 = (hi < arena.n_pkts) ? arena.off[hi] : arena.nbytes;
-            for (uint64_t k = lo; k < hi; k++) reb[k] = arena.off[k] - b0;
-            if (kmpgpu_init(&ctx[r], r % ndev)) die_gpu("kmpgpu_init");
-            if (kmpgpu_set_patterns(ctx[r], pp, pats.len, pats.n)) die_gpu("kmpgpu_set_patterns");
-            /* slots are contiguous and at least 16 bytes each, so [b0, b1) holds the whole shard */
-            if (kmpgpu_load_arena(ctx[r], arena.bytes + b0, b1 - b0, reb + lo, arena.len + lo, cnt))
-                die_gpu("kmpgpu_load_arena");
-            { kmpgpu_timing lt; if (kmpgpu_last_timing(ctx[r], &lt) == 0) h2d_ms += lt.h2d_ms; }
-            lo = hi;
+            if (job[r].rc) { fprintf(stderr, "%s: %s\n", job[r].what, job[r].err); exit(2); }
+            h2d_ms += job[r].t.h2d_ms; h2d_bytes += job[r].t.h2d_bytes;
+            if (device_extract) { arena.n_pkts += job[r].n_payloads; arena.payload_bytes += job[r].payload_bytes; }
         }
-        const char *off_path = getenv("KMPGPU_OFFSETS_FILE");
-        FILE *off_fp = NULL;
-        if (off_path && off_path[0]) {
-            off_fp = fopen(off_path, "w");
-            if (!off_fp) { perror("KMPGPU_OFFSETS_FILE"); exit(1); }
+        if (device_extract) arena.n_frames = frames.n;
+
+        /* The count reduce (mpi_dumping.c:202).  One shard per device: RCCL all-reduce over xGMI of the shards' device
+         * counters (kmpgpu_comm_*), then ONE download.  Shards that share a device (more shards than GPUs): host sum.
+         * KMPGPU_RCCL=0 forces the host sum, =1 asks for the communicator even with a single shard. */
+        const char *rccl_env = getenv("KMPGPU_RCCL");
+        kmpgpu_comm *comm = NULL;
+        kmpgpu_ctx **ctxs = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *ctxs);
+        for (int r = 0; r < shards; r++) ctxs[r] = job[r].ctx;
+        if (shards <= ndev && (shards > 1 || (rccl_env && rccl_env[0] == '1')) && !(rccl_env && rccl_env[0] == '0')) {
+            if (kmpgpu_comm_init(&comm, ctxs, shards)) die_gpu("kmpgpu_comm_init");
+            reduce_rccl = 1;
         }
-        uint64_t shard_lo = 0;
         const double t_scan0 = now_s();
         /* every shard's pass is enqueued before any result is read, so the GPUs work side by side
          * (mpi_dumping.c:198-202: all ranks count, then one reduce) */
         for (int r = 0; r < shards; r++)
-            if (kmpgpu_scan_enqueue(ctx[r], NULL)) die_gpu("kmpgpu_scan_enqueue");
-        for (int r = 0; r < shards; r++) {
-            if (kmpgpu_counts_read(ctx[r], part)) die_gpu("kmpgpu_counts_read");
-            for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];     /* mpi_dumping.c:202 MPI_SUM */
+            if (kmpgpu_scan_enqueue(ctxs[r], NULL)) die_gpu("kmpgpu_scan_enqueue");
+        if (comm) {
+            /* the shards' own counts are needed again below (offset files): keep a copy before they are summed in place */
+            if (getenv("KMPGPU_OFFSETS_FILE"))
+                for (int r = 0; r < shards; r++) {
+                    job[r].own = (uint64_t *)malloc(sizeof(uint64_t) * pats.n);
+                    if (kmpgpu_counts_read(ctxs[r], job[r].own)) die_gpu("kmpgpu_counts_read");
+                }
+            if (kmpgpu_comm_allreduce_counts(comm)) die_gpu("kmpgpu_comm_allreduce_counts");
+            if (kmpgpu_counts_read(ctxs[0], counts)) die_gpu("kmpgpu_counts_read");       /* MPI_Reduce root 0 */
+            for (int r = 1; r < shards; r++) if (kmpgpu_sync(ctxs[r])) die_gpu("kmpgpu_sync");
+        } else {
+            for (int r = 0; r < shards; r++) {
+                if (kmpgpu_counts_read(ctxs[r], part)) die_gpu("kmpgpu_counts_read");
+                for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];     /* mpi_dumping.c:202 MPI_SUM */
+                if (getenv("KMPGPU_OFFSETS_FILE")) {
+                    job[r].own = (uint64_t *)malloc(sizeof(uint64_t) * pats.n);
+                    memcpy(job[r].own, part, sizeof(uint64_t) * pats.n);
+                }
+            }
         }
-        kernel_ms = (now_s() - t_scan0) * 1e3;                              /* wall time of the concurrent passes (mpi_dumping.c:206 MPI_MAX) */
-        for (int r = 0; r < shards; r++) {
-            if (off_fp) {
-                uint64_t total = 0, found = 0;
-                if (kmpgpu_counts_read(ctx[r], part)) die_gpu("kmpgpu_counts_read");
-                for (uint32_t i = 0; i < pats.n; i++) total += part[i];
+        kernel_ms = (now_s() - t_scan0) * 1e3;                              /* wall time of the concurrent passes + reduce (mpi_dumping.c:206 MPI_MAX) */
+
+        const char *off_path = getenv("KMPGPU_OFFSETS_FILE");
+        if (off_path && off_path[0]) {
+            FILE *off_fp = fopen(off_path, "w");
+            if (!off_fp) { perror("KMPGPU_OFFSETS_FILE"); exit(1); }
+            uint64_t shard_lo = 0;                                          /* payload index of the shard's first payload */
+            for (int r = 0; r < shards; r++) {
+                uint64_t total = 0, found = 0, np = 0;
+                for (uint32_t i = 0; i < pats.n; i++) total += job[r].own[i];
                 kmpgpu_match *mm = (kmpgpu_match *)malloc(sizeof *mm * (size_t)(total ? total : 1));
-                if (!mm || kmpgpu_scan_offsets(ctx[r], mm, total, &found, NULL)) die_gpu("kmpgpu_scan_offsets");
+                if (!mm || kmpgpu_scan_offsets(ctxs[r], mm, total, &found, NULL)) die_gpu("kmpgpu_scan_offsets");
                 for (uint64_t i = 0; i < found && i < total; i++)
                     fprintf(off_fp, "%llu,%u,%u\n", (unsigned long long)(mm[i].packet + shard_lo), mm[i].offset, mm[i].pattern);
                 free(mm);
+                kmpgpu_arena_info(ctxs[r], &np, NULL);
+                shard_lo += np;
             }
-            shard_lo += arena.n_pkts / (uint64_t)shards + (r == 0 ? arena.n_pkts % (uint64_t)shards : 0);
+            fclose(off_fp);
         }
-        if (off_fp) fclose(off_fp);
         for (int r = 0; r < shards && want_stats; r++) {
             uint64_t e = 0;
-            if (kmpgpu_effective_bytes(ctx[r], &e)) die_gpu("kmpgpu_effective_bytes");
+            if (kmpgpu_effective_bytes(ctxs[r], &e)) die_gpu("kmpgpu_effective_bytes");
             eff_bytes += e;
         }
-        for (int r = 0; r < shards; r++) kmpgpu_destroy(ctx[r]);
-        free(ctx); free(reb);
+        if (comm) kmpgpu_comm_destroy(comm);
+        for (int r = 0; r < shards; r++) { kmpgpu_destroy(ctxs[r]); free(job[r].own); free(job[r].reb); }
+        free(ctxs); free(job);
     }
     const double t_finish = now_s();                                        /* serial.c:159-160 */
 
@@ -252,9 +311,9 @@ int main(int argc, char *argv[])
         uint64_t total = 0;
         for (uint32_t i = 0; i < pats.n; i++) total += counts[i];
         const double bytes = (double)arena.payload_bytes * (double)pats.n;
-        fprintf(stderr, "[kmpgpu] %llu frames, %llu payloads, %llu payload bytes, %u patterns, %d shard(s) on %d device(s)\n",
+        fprintf(stderr, "[kmpgpu] %llu frames, %llu payloads, %llu payload bytes, %u patterns, %d shard(s) on %d device(s), count reduce: %s, %llu bytes uploaded\n",
                 (unsigned long long)arena.n_frames, (unsigned long long)arena.n_pkts, (unsigned long long)arena.payload_bytes,
-                pats.n, shards, ndev);
+                pats.n, shards, ndev, reduce_rccl ? "RCCL all-reduce" : (shards > 1 ? "host sum" : "none"), (unsigned long long)h2d_bytes);
         fprintf(stderr, "[kmpgpu] kernel %.3f ms (%.2f GB/s payload x patterns, %.3g matches/s), h2d %.3f ms\n", kernel_ms,
                 bytes / (kernel_ms * 1e6), (double)total / (kernel_ms * 1e-3), h2d_ms);
         if (want_stats) {

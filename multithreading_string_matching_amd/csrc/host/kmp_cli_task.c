@@ -49,7 +49,7 @@ typedef struct shared {
 typedef struct consumer {
     shared   *sh;
     int       id;
-    uint64_t *counts;                /* [pats.n] */
+    kmpgpu_ctx *total;               /* the context that holds this shard's counts when the consumer is done */
     double    kernel_ms, h2d_ms;
     uint64_t  batches, payloads, bytes;
 } consumer;
@@ -97,13 +97,12 @@ static void *consume(void *arg)
         pthread_mutex_unlock(&sh->mu);
         if (kmpgpu_scan_enqueue(c, NULL)) die_gpu("kmpgpu_scan_enqueue");
     }
-    for (int i = 0; i < 2; i++) {
-        uint64_t *part = (uint64_t *)calloc(sh->pats->n ? sh->pats->n : 1, sizeof(uint64_t));
-        if (kmpgpu_counts_read(ctx[i], part)) die_gpu("kmpgpu_counts_read");     /* waits for the context's last scan */
-        for (uint32_t k = 0; k < sh->pats->n; k++) me->counts[k] += part[k];
-        free(part);
-        kmpgpu_destroy(ctx[i]);
-    }
+    /* the two contexts' running totals are merged on the device (openmp_task.c:172-175); the shard's counters stay there
+     * for the reduce over the shards */
+    if (kmpgpu_counts_add(ctx[0], ctx[1])) die_gpu("kmpgpu_counts_add");
+    if (kmpgpu_sync(ctx[0])) die_gpu("kmpgpu_sync");
+    kmpgpu_destroy(ctx[1]);
+    me->total = ctx[0];
     return NULL;
 }
 
@@ -166,7 +165,6 @@ int main(int argc, char *argv[])
     if (pats.n) {
         for (int r = 0; r < shards; r++) {
             cons[r].sh = &sh; cons[r].id = r;
-            cons[r].counts = (uint64_t *)calloc(pats.n, sizeof(uint64_t));
             pthread_create(&th[r], NULL, consume, &cons[r]);
         }
     }
@@ -195,17 +193,42 @@ int main(int argc, char *argv[])
     pthread_mutex_unlock(&sh.mu);
 
     uint64_t *counts = (uint64_t *)calloc(pats.n ? pats.n : 1, sizeof(uint64_t));
-    if (pats.n)
+    int reduce_rccl = 0;
+    if (pats.n) {
+        kmpgpu_ctx **tot = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *tot);
         for (int r = 0; r < shards; r++) {
             pthread_join(th[r], NULL);
-            for (uint32_t i = 0; i < pats.n; i++) counts[i] += cons[r].counts[i];                  /* openmp_task.c:172-175 */
+            tot[r] = cons[r].total;
         }
+        /* The sum over the shards (mpi_dumping.c:202): one shard per device -> RCCL all-reduce of the device counters and
+         * one download; shards that share a device -> host sum.  KMPGPU_RCCL=0 / 1 as in bin/openmp_data. */
+        const char *rccl_env = getenv("KMPGPU_RCCL");
+        kmpgpu_comm *comm = NULL;
+        if (shards <= ndev && (shards > 1 || (rccl_env && rccl_env[0] == '1')) && !(rccl_env && rccl_env[0] == '0')) {
+            if (kmpgpu_comm_init(&comm, tot, shards)) die_gpu("kmpgpu_comm_init");
+            if (kmpgpu_comm_allreduce_counts(comm)) die_gpu("kmpgpu_comm_allreduce_counts");
+            if (kmpgpu_counts_read(tot[0], counts)) die_gpu("kmpgpu_counts_read");
+            for (int r = 1; r < shards; r++) if (kmpgpu_sync(tot[r])) die_gpu("kmpgpu_sync");
+            kmpgpu_comm_destroy(comm);
+            reduce_rccl = 1;
+        } else {
+            uint64_t *part = (uint64_t *)calloc(pats.n, sizeof(uint64_t));
+            for (int r = 0; r < shards; r++) {
+                if (kmpgpu_counts_read(tot[r], part)) die_gpu("kmpgpu_counts_read");
+                for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];
+            }
+            free(part);
+        }
+        for (int r = 0; r < shards; r++) kmpgpu_destroy(tot[r]);
+        free(tot);
+    }
     const double t_finish = now_s();                                                                /* openmp_task.c:188 */
 
     kmp_report(stdout, &pats, counts, t_finish - t_start);                                         /* openmp_task.c:190-196 */
-    fprintf(stderr, "[kmpgpu] streamed %llu frames, %llu payloads, %llu payload bytes in %llu batch(es) of <= %llu MiB over %d shard(s): %.3f s, %.2f GB/s end to end\n",
+    fprintf(stderr, "[kmpgpu] streamed %llu frames, %llu payloads, %llu payload bytes in %llu batch(es) of <= %llu MiB over %d shard(s), count reduce: %s: %.3f s, %.2f GB/s end to end\n",
             (unsigned long long)frames, (unsigned long long)payloads, (unsigned long long)bytes, (unsigned long long)batches,
-            (unsigned long long)(batch_bytes >> 20), shards, t_finish - t_start, (double)bytes / (t_finish - t_start) / 1e9);
+            (unsigned long long)(batch_bytes >> 20), shards, reduce_rccl ? "RCCL all-reduce" : (shards > 1 ? "host sum" : "none"), t_finish - t_start,
+            (double)bytes / (t_finish - t_start) / 1e9);
 
     kmp_batch_close(rd);
     for (int i = 0; i < sh.n_slots; i++) {

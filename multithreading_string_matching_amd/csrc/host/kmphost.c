@@ -732,8 +732,15 @@ void kmp_report(FILE *fp, const kmp_patterns *pats, const uint64_t *counts, doub
 {
     fprintf(fp, "Printing the number of appereances of each string throughout the entire pcap file:\n");
     for (uint32_t i = 0; i < pats->n; i++)
-        if (counts[i] != 0)
+        if (counts[i] != 0) {
+            /* The reference counts in int (serial.c:101) and prints %d (serial.c:166): beyond INT_MAX its own counter
+             * has overflowed (undefined).  The line keeps the %d form -- the low 32 bits, as a wrapped int prints --
+             * and the exact 64-bit count goes to stderr. */
+            if (counts[i] > 2147483647ull)
+                fprintf(stderr, "[kmphost] warning: %s matched %llu times, more than an int holds; the report line shows the wrapped value the reference's int counter would print\n",
+                        (const char *)(pats->blob + pats->off[i]), (unsigned long long)counts[i]);
             fprintf(fp, "%s: %d times!\n", (const char *)(pats->blob + pats->off[i]), (int)counts[i]);
+        }
     fprintf(fp, "Elapsed time = %f seconds\n", elapsed_seconds);
 }
 

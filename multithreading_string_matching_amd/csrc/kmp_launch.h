@@ -62,6 +62,7 @@ hipError_t kmp_launch_validate(const uint64_t *pkt_off, const uint32_t *pkt_len,
                                uint32_t *err, unsigned long long *payload_bytes, hipStream_t st);
 hipError_t kmp_launch_synth_fill(uint8_t *arena, const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t first_pkt_id,
                                  uint64_t n, const kmp_synth_params &sp, hipStream_t st);
+hipError_t kmp_launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st);
 hipError_t kmp_launch_fixed_index(uint64_t *pkt_off, uint32_t *pkt_len, uint64_t n, uint32_t len, uint64_t stride,
                                   hipStream_t st);
 

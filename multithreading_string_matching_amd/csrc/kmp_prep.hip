@@ -480,3 +480,17 @@ hipError_t kmp_launch_fixed_index(uint64_t *pkt_off, uint32_t *pkt_len, uint64_t
     return hipGetLastError();
 }
 
+/* dst[i] += src[i]: the merge of two contexts' counters on one device (openmp_task.c:172-175, the omp atomic merge of a task's counts). */
+__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+kmp_add_counts_kernel(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+hipError_t kmp_launch_add_counts(unsigned long long *dst, const unsigned long long *src, uint32_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kmp_add_counts_kernel, dim3((n + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS), dim3(KMP_BLOCK_THREADS), 0, st, dst, src, n);
+    return hipGetLastError();
+}

@@ -9,10 +9,15 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include <dlfcn.h>
+#include <unistd.h>
+#include <rccl/rccl.h>          /* types and enums only: the library itself is opened with dlopen (kmpgpu_comm_*) */
 
 #include "kmpgpu.h"
 #include "kmp_device.h"
@@ -658,7 +663,7 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
     /* streamed captures load batch after batch: keep the device buffers when the next batch fits */
     const bool reuse = c->owned_arena && c->cap_arena >= arena_bytes && c->cap_pkts >= n_pkts && n_pkts > 0;
     release_arena(c, reuse);
-    c->last.h2d_ms = 0;
+    c->last.h2d_ms = 0; c->last.h2d_bytes = 0;
     if (n_pkts == 0) return KMPGPU_OK;
     if (arena_bytes < 16) return fail(KMPGPU_EINVAL, "arena smaller than 16 bytes");
     if (!reuse) {
@@ -676,6 +681,7 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->last.h2d_ms = ms;
+    c->last.h2d_bytes = arena_bytes + n_pkts * (sizeof(uint64_t) + sizeof(uint32_t));
     c->d_arena = (const uint8_t *)c->owned_arena;
     c->d_off = (const uint64_t *)c->owned_off;
     c->d_len = (const uint32_t *)c->owned_len;
@@ -712,13 +718,22 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
 {
     if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: ctx is NULL");
     if (n_frames && (!file_bytes || !frame_off || !frame_caplen)) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: NULL buffers");
-    for (uint64_t f = 0; f < n_frames; f++)
+    /* Only the bytes these frames span are uploaded: a shard of the frames (mpi_dumping.c:149-161 scatters shares, not
+     * the whole capture) costs its share of PCIe time and HBM, not the file's. */
+    uint64_t span_lo = file_nbytes, span_hi = 0;
+    for (uint64_t f = 0; f < n_frames; f++) {
         if (frame_off[f] > file_nbytes || frame_caplen[f] > file_nbytes - frame_off[f])
             return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: frame %llu lies outside the file buffer", (unsigned long long)f);
+        span_lo = std::min<uint64_t>(span_lo, frame_off[f]);
+        span_hi = std::max<uint64_t>(span_hi, frame_off[f] + frame_caplen[f]);
+    }
+    if (span_hi < span_lo) span_lo = span_hi = 0;
+    span_lo &= ~(uint64_t)15;                           /* keeps the frames' alignment relative to the device buffer */
+    const uint64_t span = span_hi - span_lo;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     release_arena(c);
-    c->last.h2d_ms = 0;
+    c->last.h2d_ms = 0; c->last.h2d_bytes = 0;
     if (n_payloads) *n_payloads = 0;
     if (n_frames == 0) return KMPGPU_OK;
 
@@ -736,23 +751,25 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
         if (d_tot) (void)hipFree(d_tot);
     };
 #define KMP_TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(KMPGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
-    KMP_TRY2(hipMalloc(&d_file, file_nbytes + 64));
+    KMP_TRY2(hipMalloc(&d_file, span + 64));
+    const uint8_t *d_base = d_file - span_lo;           /* d_base[frame_off[f] ...] lies inside d_file for every frame given */
     KMP_TRY2(hipMalloc(&d_foff, n_frames * sizeof(uint64_t)));
     KMP_TRY2(hipMalloc(&d_cl, n_frames * sizeof(uint32_t)));
     KMP_TRY2(hipMalloc(&d_ws, kmp_extract_ws_bytes(n_frames)));
     KMP_TRY2(hipMalloc(&d_tot, 2 * sizeof(unsigned long long)));
     KMP_TRY2(hipEventRecord(c->ev[0], c->stream));
-    KMP_TRY2(hipMemcpyAsync(d_file, file_bytes, file_nbytes, hipMemcpyHostToDevice, c->stream));
+    KMP_TRY2(hipMemcpyAsync(d_file, file_bytes + span_lo, span, hipMemcpyHostToDevice, c->stream));
     KMP_TRY2(hipMemcpyAsync(d_foff, frame_off, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     KMP_TRY2(hipMemcpyAsync(d_cl, frame_caplen, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     KMP_TRY2(hipEventRecord(c->ev[1], c->stream));
-    KMP_TRY2(kmp_launch_extract_phase1(d_file, d_foff, d_cl, n_frames, tcp, d_ws, d_tot, c->stream));
+    KMP_TRY2(kmp_launch_extract_phase1(d_base, d_foff, d_cl, n_frames, tcp, d_ws, d_tot, c->stream));
     unsigned long long tot[2] = {0, 0};
     KMP_TRY2(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
     KMP_TRY2(hipStreamSynchronize(c->stream));
     float ms = 0;
     KMP_TRY2(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->last.h2d_ms = ms;
+    c->last.h2d_bytes = span + n_frames * (sizeof(uint64_t) + sizeof(uint32_t));
     const uint64_t n_pkts = tot[1], arena_bytes = tot[0] + 64;
     if (n_pkts) {
         KMP_TRY2(hipMalloc(&c->owned_arena, arena_bytes));
@@ -761,7 +778,7 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
         KMP_TRY2(hipMalloc(&d_src, n_pkts * sizeof(uint64_t)));
         c->cap_arena = arena_bytes; c->cap_pkts = n_pkts;
         KMP_TRY2(hipMemsetAsync((uint8_t *)c->owned_arena + tot[0], 0, 64, c->stream));
-        KMP_TRY2(kmp_launch_extract_phase2(d_file, d_foff, n_frames, d_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
+        KMP_TRY2(kmp_launch_extract_phase2(d_base, d_foff, n_frames, d_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
                                            (uint32_t *)c->owned_len, d_src, c->stream));
         KMP_TRY2(hipStreamSynchronize(c->stream));
     }
@@ -826,6 +843,17 @@ int kmpgpu_counts_reset(kmpgpu_ctx *c)
     if (!c->d_counts) return fail(KMPGPU_ESTATE, "kmpgpu_counts_reset: no patterns set");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(unsigned long long) * (c->n_pat ? c->n_pat : 1), c->stream));
+    return KMPGPU_OK;
+}
+
+int kmpgpu_counts_add(kmpgpu_ctx *dst, kmpgpu_ctx *src)
+{
+    if (!dst || !src || dst == src) return fail(KMPGPU_EINVAL, "kmpgpu_counts_add: bad arguments");
+    if (dst->device != src->device) return fail(KMPGPU_EINVAL, "kmpgpu_counts_add: the contexts sit on devices %d and %d (sum across devices with kmpgpu_comm_allreduce_counts)", dst->device, src->device);
+    if (!dst->d_counts || !src->d_counts || dst->n_pat != src->n_pat) return fail(KMPGPU_ESTATE, "kmpgpu_counts_add: the contexts do not hold the same patterns");
+    HIP_TRY(hipSetDevice(dst->device));
+    HIP_TRY(hipStreamSynchronize(src->stream));                 /* src's passes have landed in its counters */
+    HIP_TRY(kmp_launch_add_counts(dst->d_counts, src->d_counts, dst->n_pat, dst->stream));
     return KMPGPU_OK;
 }
 
@@ -914,23 +942,29 @@ int kmpgpu_scan_offsets(kmpgpu_ctx *c, kmpgpu_match *out, uint64_t cap, uint64_t
     HIP_TRY(hipSetDevice(c->device));
     *n_found = 0;
     void *d_out = nullptr;
-    unsigned long long *d_cnt = nullptr;
+    unsigned long long *d_cnt = nullptr;             /* [0] matches found; [1 ..] this pass's counts */
+    const size_t np = c->n_pat ? c->n_pat : 1;
     HIP_TRY(hipMalloc(&d_out, (cap ? cap : 1) * sizeof(kmpgpu_match)));
-    hipError_t e = hipMalloc(&d_cnt, sizeof(unsigned long long));
+    hipError_t e = hipMalloc(&d_cnt, (1 + np) * sizeof(unsigned long long));
     int rc = KMPGPU_OK;
     unsigned long long found = 0;
     if (e != hipSuccess) rc = fail(KMPGPU_EHIP, "hipMalloc failed: %s", hipGetErrorString(e));
-    if (!rc && (e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), c->stream)) != hipSuccess)
+    if (!rc && (e = hipMemsetAsync(d_cnt, 0, (1 + np) * sizeof(unsigned long long), c->stream)) != hipSuccess)
         rc = fail(KMPGPU_EHIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     if (!rc) {
+        /* The pass writes its counts to a buffer of its own and never accumulates: the context's counters (a running
+         * total under KMPGPU_OPT_ACCUMULATE, or the result of a count reduce) are left as they are. */
         EmitTarget t;
         t.out = d_out; t.counter = d_cnt; t.cap = cap;
-        rc = enqueue_pass(c, nullptr, nullptr, &t);
+        const int acc = c->accumulate;
+        c->accumulate = 0;
+        rc = enqueue_pass(c, nullptr, d_cnt + 1, &t);
+        c->accumulate = acc;
     }
     if (!rc && (e = hipMemcpyAsync(&found, d_cnt, sizeof found, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         rc = fail(KMPGPU_EHIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
     if (!rc && c->n_pat && counts_out &&
-        (e = hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint64_t) * c->n_pat, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
+        (e = hipMemcpyAsync(c->h_counts, d_cnt + 1, sizeof(uint64_t) * c->n_pat, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         rc = fail(KMPGPU_EHIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
     if (!rc && (e = hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail(KMPGPU_EHIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
     if (!rc) {
@@ -1009,6 +1043,178 @@ int kmpgpu_arena_download(kmpgpu_ctx *c, uint8_t *arena_out, uint64_t arena_cap,
     if (pkt_off_out) HIP_TRY(hipMemcpy(pkt_off_out, c->d_off, c->n_pkts * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (pkt_len_out) HIP_TRY(hipMemcpy(pkt_len_out, c->d_len, c->n_pkts * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return KMPGPU_OK;
+}
+
+}  // extern "C"
+
+/* ---- RCCL count reduce (mpi_dumping.c:202) -------------------------------------------------------------- */
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load()
+{
+    static int state = 0;           /* 0 untried, 1 loaded, -1 failed */
+    if (state == 1) return KMPGPU_OK;
+    if (state == -1) return fail(KMPGPU_EHIP, "librccl.so could not be loaded");
+    /* RCCL writes its version banner and NCCL_DEBUG output to stdout unless told otherwise; stdout belongs to the
+     * caller (the drop-in programs' report, serial.c:163-169, is compared byte for byte) */
+    setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { state = -1; return fail(KMPGPU_EHIP, "cannot load librccl.so: %s", dlerror()); }
+    g_rccl.handle = h;
+#define KMP_RCCL_SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(h, name); \
+        if (!g_rccl.field) { state = -1; return fail(KMPGPU_EHIP, "librccl.so lacks %s", name); } } while (0)
+    KMP_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    KMP_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    KMP_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    KMP_RCCL_SYM(AllReduce, "ncclAllReduce");
+    KMP_RCCL_SYM(GroupStart, "ncclGroupStart");
+    KMP_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    KMP_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    KMP_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef KMP_RCCL_SYM
+    state = 1;
+    return KMPGPU_OK;
+}
+/* RCCL prints its version banner (NCCL_DEBUG=VERSION and above) with printf on the first communicator: stdout belongs
+ * to the caller -- the drop-in programs' report (serial.c:163-169) is compared byte for byte -- so file descriptor 1
+ * points at stderr while a communicator is being created.  (Another thread of the caller that writes to stdout in
+ * exactly that window lands on stderr too.) */
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr()
+    {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0 && dup2(2, 1) < 0) { close(saved); saved = -1; }
+    }
+    ~StdoutToStderr()
+    {
+        if (saved < 0) return;
+        fflush(stdout);
+        (void)dup2(saved, 1);
+        close(saved);
+    }
+};
+#define RCCL_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return fail(KMPGPU_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+}  // namespace
+
+struct kmpgpu_comm {
+    std::vector<kmpgpu_ctx *> ctx;          /* the local ranks' contexts */
+    std::vector<ncclComm_t>   comm;         /* one communicator handle per local rank */
+    int n_ranks = 0;
+};
+
+extern "C" {
+
+int kmpgpu_device_of(kmpgpu_ctx *c) { return c ? c->device : fail(KMPGPU_EINVAL, "kmpgpu_device_of: ctx is NULL"); }
+
+int kmpgpu_comm_init(kmpgpu_comm **out, kmpgpu_ctx *const *ctx, int n_ctx)
+{
+    if (!out || !ctx || n_ctx < 1) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: bad arguments");
+    *out = nullptr;
+    std::vector<int> devs;
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctx[i]) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: context %d is NULL", i);
+        if (ctx[i]->n_pat != ctx[0]->n_pat) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: context %d holds %u patterns, context 0 %u", i, ctx[i]->n_pat, ctx[0]->n_pat);
+        for (int d : devs)
+            if (d == ctx[i]->device)
+                return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: two contexts on device %d (one rank per device: sum the counts of contexts that share a GPU on the host)", d);
+        devs.push_back(ctx[i]->device);
+    }
+    int rc = rccl_load();
+    if (rc) return rc;
+    kmpgpu_comm *k = new (std::nothrow) kmpgpu_comm();
+    if (!k) return fail(KMPGPU_ENOMEM, "kmpgpu_comm_init: out of host memory");
+    k->ctx.assign(ctx, ctx + n_ctx);
+    k->comm.assign((size_t)n_ctx, nullptr);
+    k->n_ranks = n_ctx;
+    ncclResult_t r;
+    { StdoutToStderr guard; r = g_rccl.CommInitAll(k->comm.data(), n_ctx, devs.data()); }
+    if (r != ncclSuccess) { delete k; return fail(KMPGPU_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r)); }
+    *out = k;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(KMPGPU_EINVAL, "kmpgpu_comm_unique_id: NULL argument");
+    static_assert(sizeof(ncclUniqueId) == KMPGPU_COMM_ID_BYTES, "KMPGPU_COMM_ID_BYTES");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId id;
+    { StdoutToStderr guard; RCCL_TRY(g_rccl.GetUniqueId(&id)); }
+    memcpy(id_out, &id, sizeof id);
+    return KMPGPU_OK;
+}
+
+int kmpgpu_comm_init_rank(kmpgpu_comm **out, kmpgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id)
+{
+    if (!out || !ctx || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init_rank: bad arguments");
+    *out = nullptr;
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    kmpgpu_comm *k = new (std::nothrow) kmpgpu_comm();
+    if (!k) return fail(KMPGPU_ENOMEM, "kmpgpu_comm_init_rank: out of host memory");
+    k->ctx.push_back(ctx);
+    k->comm.push_back(nullptr);
+    k->n_ranks = n_ranks;
+    ncclResult_t r;
+    { StdoutToStderr guard; r = g_rccl.CommInitRank(&k->comm[0], n_ranks, id, rank); }
+    if (r != ncclSuccess) { delete k; return fail(KMPGPU_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    *out = k;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_comm_allreduce_counts(kmpgpu_comm *k)
+{
+    if (!k) return fail(KMPGPU_EINVAL, "kmpgpu_comm_allreduce_counts: comm is NULL");
+    const uint32_t n = k->ctx[0]->n_pat;
+    for (kmpgpu_ctx *c : k->ctx) {
+        if (!c->d_counts) return fail(KMPGPU_ESTATE, "kmpgpu_comm_allreduce_counts: a context has no patterns set");
+        if (c->n_pat != n) return fail(KMPGPU_EINVAL, "kmpgpu_comm_allreduce_counts: the contexts hold different numbers of patterns");
+    }
+    if (n == 0) return KMPGPU_OK;
+    RCCL_TRY(g_rccl.GroupStart());
+    for (size_t i = 0; i < k->ctx.size(); i++) {
+        kmpgpu_ctx *c = k->ctx[i];
+        ncclResult_t r = g_rccl.AllReduce(c->d_counts, c->d_counts, n, ncclUint64, ncclSum, k->comm[i], c->stream);
+        if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(KMPGPU_EHIP, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r)); }
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    return KMPGPU_OK;
+}
+
+void kmpgpu_comm_destroy(kmpgpu_comm *k)
+{
+    if (!k) return;
+    for (size_t i = 0; i < k->comm.size(); i++) {
+        if (!k->comm[i]) continue;
+        (void)hipSetDevice(k->ctx[i]->device);
+        (void)hipStreamSynchronize(k->ctx[i]->stream);
+        (void)g_rccl.CommDestroy(k->comm[i]);
+    }
+    delete k;
 }
 
 }  // extern "C"

@@ -139,6 +139,18 @@ class GpuMatcher:
         ptr = d_counts.data_ptr() if d_counts is not None else None
         gpu_check(self._g.kmpgpu_scan_enqueue(self._ctx, ptr), "kmpgpu_scan_enqueue")
 
+    def counts_read(self) -> np.ndarray:
+        """Wait for the context's stream and read its own counts buffer (after scan_enqueue() / a count reduce)."""
+        n = len(self.patterns)
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        gpu_check(self._g.kmpgpu_counts_read(self._ctx, out.ctypes.data_as(u64p)), "kmpgpu_counts_read")
+        return out[:n]
+
+    def last_timing(self) -> Timing:
+        t = Timing()
+        gpu_check(self._g.kmpgpu_last_timing(self._ctx, C.byref(t)), "kmpgpu_last_timing")
+        return t
+
     def counts_reset(self) -> None:
         gpu_check(self._g.kmpgpu_counts_reset(self._ctx), "kmpgpu_counts_reset")
 
@@ -193,6 +205,49 @@ class GpuMatcher:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class GpuComm:
+    """RCCL count reduce behind the C-ABI (kmpgpu_comm_*): replaces MPI_Reduce(..., MPI_SUM ...) of mpi_dumping.c:202.
+
+    ``GpuComm(matchers)``: all ranks in this process, one matcher per device (ncclCommInitAll).
+    ``GpuComm.from_rank(matcher, n_ranks, rank, unique_id)``: one process per GPU; ``GpuComm.unique_id()`` makes the id."""
+
+    def __init__(self, matchers: Sequence["GpuMatcher"]):
+        self._g = _lib.gpu_lib()
+        self._comm = C.c_void_p()
+        self._matchers = list(matchers)
+        arr = (C.c_void_p * len(self._matchers))(*[m._ctx for m in self._matchers])
+        gpu_check(self._g.kmpgpu_comm_init(C.byref(self._comm), arr, len(self._matchers)), "kmpgpu_comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        gpu_check(_lib.gpu_lib().kmpgpu_comm_unique_id(buf), "kmpgpu_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_rank(cls, matcher: "GpuMatcher", n_ranks: int, rank: int, unique_id: bytes) -> "GpuComm":
+        self = cls.__new__(cls)
+        self._g = _lib.gpu_lib()
+        self._comm = C.c_void_p()
+        self._matchers = [matcher]
+        gpu_check(self._g.kmpgpu_comm_init_rank(C.byref(self._comm), matcher._ctx, n_ranks, rank, C.c_char_p(unique_id)), "kmpgpu_comm_init_rank")
+        return self
+
+    def allreduce_counts(self) -> None:
+        gpu_check(self._g.kmpgpu_comm_allreduce_counts(self._comm), "kmpgpu_comm_allreduce_counts")
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None) is not None and self._comm.value:
+            self._g.kmpgpu_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def count_matches(patterns: Sequence[bytes], arena: HostArena, device: int = 0, **options) -> np.ndarray:

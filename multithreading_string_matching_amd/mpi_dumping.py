@@ -74,39 +74,67 @@ def main(argv=None) -> int:
         torch.cuda.set_stream(stream)
         with GpuMatcher(dev_index) as m:
             m.set_stream(stream.cuda_stream)
-            flag = torch.zeros(1, dtype=torch.int64, device=dev)
-            try:
-                if patterns:
-                    m.set_patterns(patterns)
-                m.load_pcap_frames(pcap_path, proto, rank, world)       # this rank's frames: extraction on the GPU
-            except KmpHostError as e:                    # mpi_dumping.c:110-114,135-142: message on rank 0, every rank leaves with 0
-                if rank == 0:
-                    msg = str(e)
-                    print(msg[:msg.rfind(" (")] if " (" in msg else msg, file=sys.stderr)
-                flag += 1
-            kd.reduce_counts(flag)
-            if int(flag.item()):
-                return 0
-            kd.barrier()                                 # mpi_dumping.c:167-168
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            counts = torch.zeros(max(len(patterns), 1), dtype=torch.int64, device=dev)
-            if patterns:
-                m.scan_enqueue(counts)                   # mpi_dumping.c:198-200 (extraction already done on the device)
-            kd.reduce_counts(counts)                     # mpi_dumping.c:202 MPI_SUM
-            total = counts.cpu().tolist()[:len(patterns)]
-            elapsed = kd.max_over_ranks(time.perf_counter() - t0, device=dev)      # mpi_dumping.c:206 MPI_MAX
-            if rank == 0:                                # mpi_dumping.c:208-214
-                sys.stdout.write(host.format_report(patterns, total))
-                sys.stdout.write(f"Elapsed time = {elapsed:f} seconds\n")
-                sys.stdout.flush()
-    except KmpGpuError as e:
+            rc = count_and_report(m, patterns, pcap_path, proto, rank, world, dev)
+    except KmpGpuError as e:                             # outside the flag protocol (context creation): nobody waits for this rank yet
         print(f"mpi_dumping: rank {rank}: {e}", file=sys.stderr)
         rc = 2
     finally:
         if world > 1 and dist.is_initialized():
             dist.destroy_process_group()
     return rc
+
+
+HOST_ERROR, GPU_ERROR = 1, 1 << 32
+
+
+def count_and_report(m, patterns, pcap_path, proto, rank, world, dev, out=None) -> int:
+    """Load this rank's frames, count, reduce, report (mpi_dumping.c:104-214) on matcher ``m``.
+
+    Every failure of the load stage takes part in ONE all-reduced flag (mpi_dumping.c:135-142 broadcasts such a flag),
+    so that no rank is left waiting in a collective for a rank that has given up: a capture that cannot be read
+    (KmpHostError; message on rank 0, every rank leaves with 0 like the reference) and a GPU-side failure on any rank
+    (KmpGpuError: out of device memory, wrong device ...; every rank leaves with 2)."""
+    import torch
+
+    from . import dist as kd
+    from . import host
+    from ._lib import KmpGpuError, KmpHostError
+
+    out = sys.stdout if out is None else out
+    flag = torch.zeros(1, dtype=torch.int64, device=dev)
+    try:
+        if patterns:
+            m.set_patterns(patterns)
+        m.load_pcap_frames(pcap_path, proto, rank, world)       # this rank's frames: extraction on the GPU
+    except KmpHostError as e:                            # mpi_dumping.c:110-114,135-142: message on rank 0, every rank leaves with 0
+        if rank == 0:
+            msg = str(e)
+            print(msg[:msg.rfind(" (")] if " (" in msg else msg, file=sys.stderr)
+        flag += HOST_ERROR
+    except KmpGpuError as e:
+        print(f"mpi_dumping: rank {rank}: {e}", file=sys.stderr)
+        flag += GPU_ERROR
+    kd.reduce_counts(flag)
+    failed = int(flag.item())
+    if failed >= GPU_ERROR:
+        return 2
+    if failed:
+        return 0
+    kd.barrier()                                         # mpi_dumping.c:167-168
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = torch.zeros(max(len(patterns), 1), dtype=torch.int64, device=dev)
+    if patterns:
+        m.scan_enqueue(counts)                           # mpi_dumping.c:198-200 (extraction already done on the device)
+    kd.reduce_counts(counts)                             # mpi_dumping.c:202 MPI_SUM
+    total = counts.cpu().tolist()[:len(patterns)]
+    elapsed = kd.max_over_ranks(time.perf_counter() - t0, device=dev)      # mpi_dumping.c:206 MPI_MAX
+    if rank == 0:                                        # mpi_dumping.c:208-214
+        out.write(host.format_report(patterns, total))
+        out.write(f"Elapsed time = {elapsed:f} seconds\n")
+        out.flush()
+    return 0
 
 
 if __name__ == "__main__":

@@ -85,3 +85,64 @@ def test_reduce_without_process_group_is_identity():
     assert max_over_ranks(3.5) == 3.5
     with pytest.raises(TypeError):
         reduce_counts(torch.zeros(3, dtype=torch.int32))
+
+
+class _FakeMatcher:
+    """Stands in for GpuMatcher in the CPU test of mpi_dumping's rank protocol: the load stage fails as told."""
+
+    def __init__(self, fail, local):
+        self.fail, self.local = fail, local
+
+    def set_patterns(self, patterns):
+        self.n = len(patterns)
+
+    def load_pcap_frames(self, path, proto, rank, world):
+        from multithreading_string_matching_amd._lib import KmpGpuError, KmpHostError
+        if self.fail == "gpu":
+            raise KmpGpuError("kmpgpu_load_frames failed (-1): hipMalloc failed: out of memory")
+        if self.fail == "host":
+            raise KmpHostError("error reading pcap file: no such file (-1)")
+
+    def scan_enqueue(self, counts):
+        counts[: self.n] = torch.tensor(self.local[: self.n], dtype=torch.int64)
+
+
+def _protocol_worker(rank, world, port, fail_on, q):
+    import io
+    import sys
+    sys.path.insert(0, ROOT)
+    from multithreading_string_matching_amd.mpi_dumping import count_and_report
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fail = fail_on.get(rank)
+        out = io.StringIO()
+        rc = count_and_report(_FakeMatcher(fail, [1 + rank, 10, 0]), [b"aa", b"bb", b"cc"], "x.pcap", "udp", rank, world, torch.device("cpu"), out=out)
+        q.put((rank, rc, out.getvalue()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_on,want_rc", [({}, 0), ({1: "gpu"}, 2), ({0: "host", 1: "host"}, 0), ({0: "host", 1: "gpu"}, 2)])
+def test_mpi_dumping_rank_protocol_never_leaves_a_rank_waiting(fail_on, want_rc):
+    """A failure of the load stage on ONE rank (KmpGpuError: e.g. hipMalloc) must reach every rank through the all-reduced
+    flag: all ranks return (nobody hangs in a collective), with 2 for a GPU failure and 0 for an unreadable capture
+    (mpi_dumping.c:135-142).  Two gloo ranks on the CPU, the matcher faked."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, fail_on, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [want_rc, want_rc]
+    if not fail_on:
+        assert res[0][2].startswith("Printing the number of appereances") and "aa: 3 times!" in res[0][2] and "bb: 20 times!" in res[0][2]
+        assert "cc:" not in res[0][2] and res[1][2] == ""
+    else:
+        assert res[0][2] == "" and res[1][2] == ""

@@ -1025,3 +1025,161 @@ def test_cli_pcap_route_equals_arena_route(gm, tmp_path):
     assert r.returncode == 0, r.stderr
     planted = K.synth_count_planted(sp, n, 1500)
     assert _strip_elapsed(r.stdout) == K.format_report([needle], [planted])
+
+
+# ------------------------------------------------------------------------------------------------
+# the count reduce over GPUs through the C-ABI (RCCL, kmpgpu_comm_*; mpi_dumping.c:202)
+# ------------------------------------------------------------------------------------------------
+def test_rccl_count_reduce_through_the_c_abi(gm, fixture_counts, tokens):
+    """A communicator over the devices of this box (one here): kmpgpu_scan_enqueue -> kmpgpu_comm_allreduce_counts
+    (ncclAllReduce, uint64 sum, in place over the context's counts buffer, on its stream) -> kmpgpu_counts_read gives
+    the counts serial.c prints.  Both ways of building the communicator: all ranks in this process
+    (ncclCommInitAll) and rank 0 of 1 from a unique id (one process per GPU)."""
+    fx = fixture_counts["fixtures"]["udp_1000.pcap:udp"]
+    arena = K.HostArena.from_pcap(os.path.join(DATA, "udp_1000.pcap"), "udp")
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(tokens)
+    gm.load_arena(arena)
+    with K.GpuComm([gm]) as comm:
+        for _ in range(3):                         # the buffer is overwritten by every pass, then reduced in place
+            gm.scan_enqueue()
+            comm.allreduce_counts()
+            assert gm.counts_read().tolist() == fx["counts"]
+    uid = K.GpuComm.unique_id()
+    assert len(uid) == 128
+    with K.GpuComm.from_rank(gm, 1, 0, uid) as comm:
+        gm.scan_enqueue()
+        comm.allreduce_counts()
+        assert gm.counts_read().tolist() == fx["counts"]
+    # two contexts on one device are refused: one rank per GPU
+    m2 = GpuMatcher(0)
+    try:
+        m2.set_patterns(tokens)
+        with pytest.raises(K.KmpGpuError, match="two contexts on device"):
+            K.GpuComm([gm, m2])
+        m2.set_patterns(tokens[:3])
+    finally:
+        m2.close()
+
+
+def test_cli_rccl_reduce(fixture_counts, tokens):
+    """bin/openmp_data with the RCCL reduce forced on a single shard: same stdout, and stderr names the reduce."""
+    fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
+    exe = os.path.join(_lib.BINDIR, "openmp_data")
+    for extract in ("0", "1"):
+        env = dict(os.environ, KMPGPU_RCCL="1", KMPGPU_DEVICE_EXTRACT=extract)
+        r = subprocess.run([exe, os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), "1", "udp"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+        assert "count reduce: RCCL all-reduce" in r.stderr
+    # the streamed form: the two contexts of a shard are merged on the device (kmpgpu_counts_add), then the same reduce
+    env = dict(os.environ, KMPGPU_RCCL="1", KMPGPU_BATCH_BYTES="1048576")
+    r = subprocess.run([os.path.join(_lib.BINDIR, "openmp_task"), os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), "1", "udp"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"]) and "count reduce: RCCL all-reduce" in r.stderr
+    # more shards than devices: the shards share the GPU and are summed on the host
+    r = subprocess.run([exe, os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), "3", "udp"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+    assert "count reduce: host sum" in r.stderr or K.device_count() >= 3
+
+
+def test_cli_stdout_is_the_literal_golden_text():
+    """bin/serial on udp_1000.pcap against the text of SURVEY App. B, byte for byte (tests/golden/stdout_udp_1000_udp.txt)."""
+    golden = open(os.path.join(os.path.dirname(DATA), "stdout_udp_1000_udp.txt")).read()
+    for prog, extra in (("serial", ["udp"]), ("openmp_data", ["2", "udp"]), ("openmp_task", ["2", "udp"])):
+        r = _run(prog, os.path.join(DATA, "udp_1000.pcap"), os.path.join(DATA, "strings.txt"), *extra)
+        assert r.returncode == 0, r.stderr
+        assert _strip_elapsed(r.stdout) == golden, prog
+
+
+def test_frame_shards_upload_only_their_span(gm, fixture_counts, tokens):
+    """kmpgpu_load_frames with a shard of the frames (mpi_dumping.c:149-161): the bytes copied to the device are the
+    shard's span of the file, about file / P, and the shards' arenas and counts add up to the whole capture's."""
+    path = os.path.join(DATA, "big_udp.pcap")
+    fsize = os.path.getsize(path)
+    fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(tokens)
+    n_all, frames = gm.load_pcap_frames(path, "udp")
+    whole = gm.arena_download()
+    assert gm.scan()[0].tolist() == fx["counts"] and n_all == fx["payloads"]
+    for world in (2, 3):
+        total = np.zeros(len(tokens), dtype=np.uint64)
+        pieces, n_sum = [], 0
+        for rank in range(world):
+            n, fr = gm.load_pcap_frames(path, "udp", rank=rank, world=world)
+            assert fr == frames
+            up = gm.last_timing().h2d_bytes
+            assert up <= fsize / world * 1.25 + 12 * frames and up >= fsize / world * 0.6, (world, rank, up, fsize)
+            total += gm.scan()[0]
+            a, off, ln = gm.arena_download()
+            pieces.append((a, off, ln))
+            n_sum += n
+        assert total.tolist() == fx["counts"] and n_sum == n_all
+        # payload by payload the shards hold what the whole capture's arena holds
+        k = 0
+        for a, off, ln in pieces:
+            for o, l in zip(off, ln):
+                assert int(l) == int(whole[2][k]) and a[int(o):int(o) + int(l)].tobytes() == whole[0][int(whole[1][k]):int(whole[1][k]) + int(l)].tobytes()
+                k += 1
+        assert k == n_all
+
+
+def test_offsets_pass_leaves_the_running_totals_alone(gm, oracle):
+    """KMPGPU_OPT_ACCUMULATE (streamed batches) + kmpgpu_scan_offsets: the offsets pass returns ITS counts and does not add
+    the batch to the context's counters a second time."""
+    rng = random.Random(5)
+    payloads = [bytes(rng.choice(b"abc") for _ in range(rng.randrange(0, 900))) for _ in range(300)]
+    pats = [b"ab", b"abcab", b"c", b"abcabcabcabcabcabca"]
+    arena = K.HostArena.from_payloads(payloads)
+    want, _ = oracle.count(arena.bytes, arena.off, arena.len, pats)
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    gm.load_arena(arena)
+    gm.set_option(6, 1)                            # KMPGPU_OPT_ACCUMULATE
+    try:
+        gm.counts_reset()
+        gm.scan_enqueue()
+        got, found, counts = gm.scan_offsets(int(want.sum()) + 5)
+        assert counts.tolist() == want.tolist() and found == int(want.sum())
+        assert gm.counts_read().tolist() == want.tolist()
+        gm.scan_enqueue()
+        assert gm.counts_read().tolist() == (2 * want).tolist()
+    finally:
+        gm.set_option(6, 0)
+
+
+def test_borrowed_arena_must_be_reattached_after_a_rewrite(gm, oracle):
+    """kmpgpu_attach_arena snapshots derived state (start bitmap, wavefront plan, padding check): a borrowed arena that is
+    refilled in place has to be attached again (include/kmpgpu.h); after the re-attach the counts are those of the new
+    contents, whatever the new packet boundaries are."""
+    import torch
+    rng = random.Random(9)
+    pats = [b"ab", b"abca", b"abcabcabcabcab"]
+    first = [bytes(rng.choice(b"abc") for _ in range(rng.randrange(1, 600))) for _ in range(400)]
+    second = [bytes(rng.choice(b"abc") for _ in range(rng.randrange(1, 200))) for _ in range(900)]
+    a1, a2 = K.HostArena.from_payloads(first), K.HostArena.from_payloads(second)
+    cap = max(a1.nbytes, a2.nbytes)
+    d_arena = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    d_off = torch.zeros(max(a1.n_pkts, a2.n_pkts), dtype=torch.int64, device="cuda")
+    d_len = torch.zeros(max(a1.n_pkts, a2.n_pkts), dtype=torch.int32, device="cuda")
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    for a in (a1, a2, a1):
+        d_arena.zero_()
+        d_arena[: a.nbytes] = torch.from_numpy(np.array(a.bytes))
+        d_off[: a.n_pkts] = torch.from_numpy(a.off.astype(np.int64))
+        d_len[: a.n_pkts] = torch.from_numpy(a.len.astype(np.int32))
+        torch.cuda.synchronize()
+        gm.attach_arena(d_arena, d_off[: a.n_pkts], d_len[: a.n_pkts])
+        want, _ = oracle.count(a.bytes, a.off, a.len, pats)
+        for kernel in (KERNEL_AUTO, KERNEL_FUSED):
+            gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
+            assert gm.scan()[0].tolist() == want.tolist()
+        gm.set_option(OPT_FUSED, 2)

@@ -314,3 +314,40 @@ def test_cli_fails_loudly_without_gpu():
     assert r.returncode == 2 and r.stdout == "" and r.stderr.strip() != ""      # no CPU fallback
     with pytest.raises(K.KmpGpuError):
         K.GpuMatcher(0)
+
+
+def test_report_is_the_reference_text_and_flags_int_overflow(tmp_path, tokens):
+    """kmp_report (serial.c:163-169) against the literal stdout SURVEY App. B records for udp_1000.pcap, and the stderr
+    warning when a count no longer fits the reference's int counter (serial.c:101,166)."""
+    import ctypes as C
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "stdout_udp_1000_udp.txt")).read()
+    counts = [0] * len(tokens)
+    for i, c in {0: 198, 1: 89, 2: 159, 3: 118, 15: 197, 53: 4, 78: 158, 82: 4}.items():
+        counts[i] = c
+    assert K.format_report(tokens, counts) == golden
+    # the C formatter, through a child process so that its stdio streams can be captured
+    code = f"""
+import ctypes as C, sys, os
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from multithreading_string_matching_amd import _lib
+L = _lib.host_lib()
+p = _lib.Patterns()
+assert L.kmp_patterns_load({os.path.join(DATA, 'strings.txt')!r}.encode(), C.byref(p)) == 0
+counts = np.array({counts!r}, dtype=np.uint64)
+if len(sys.argv) > 1: counts[5] = 3_000_000_000
+libc = C.CDLL(None)
+libc.fdopen.restype = C.c_void_p
+fp = libc.fdopen(1, b"w")
+L.kmp_report(C.c_void_p(fp), C.byref(p), counts.ctypes.data_as(_lib.u64p), C.c_double(0.5))
+libc.fflush(C.c_void_p(fp))
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == golden + "Elapsed time = 0.500000 seconds\n" and "warning" not in r.stderr
+    r = subprocess.run([sys.executable, "-c", code, "overflow"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "udp: -1294967296 times!" in r.stdout and "udp matched 3000000000 times" in r.stderr
