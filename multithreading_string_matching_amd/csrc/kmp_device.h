@@ -28,30 +28,40 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 
 /* Tables of the fused multi-pattern kernel (kmp_scan_multi_kernel), one blob of uint32 words built on
  * the host (kmpgpu_set_patterns) and copied into LDS by every block:
- *   [0, 512)         1024 x uint16: first entry of the bucket hash(b0 | b1 << 8), 0xFFFF = empty
- *   [512, 1024)      entries, uint32 each: unique-pattern id (bits 0-7) | third pattern byte << 8 (0 when the
- *                    pattern has 2 bytes: nothing to pre-check) | 0x40000000 for a pattern of more than 20 bytes |
- *                    0x80000000 on the last entry of a bucket
- *   [1024, 3072)     64 Kbit filter over the first THREE text bytes: bit h = KMP_MULTI_BIT(b0 | b1 << 8 |
- *                    b2 << 16) (byte h >> 3, bit h & 7) is set for every pattern of 3+ bytes, and for all 256
- *                    values of b2 for a 2-byte pattern (so one lookup serves both).  The multiplicative
- *                    hash also spreads text, whose bytes share their high bits, over the LDS banks.
- *   [3072, ...)      one 12-word record per unique pattern: its first 20 bytes as 5 dwords, 5 byte masks, m, and for a
- *                    pattern of more than 20 bytes its index + 1 (the rest is compared against kmp_pattern_dev.pat)
- * The first 3072 words live in static LDS (their offsets fold into the ds_read offset field). */
+ *   [0, 2048)        two words per bucket KMP_MULTI_HASH(key): its first entry itself, then where its further entries start
+ *                    (bits 0-15) | number of entries (bits 16-31) -- one 8-byte read decides a bucket of one pattern.
+ *                    key = b0 | b1 << 8 | (b2 & 31) << 16 (bucket mask KMP_MULTI_KEYMASK): patterns that only share their
+ *                    first two bytes ("de": depth, decode, defrag, detector, detail) land in different buckets, so a
+ *                    walk is one entry long as a rule; a 2-byte pattern is entered under all 32 values of b2 & 31.  A
+ *                    group with more than KMP_MULTI_MAX_TWO 2-byte patterns is bucketed by b0 | b1 << 8 alone (mask 0xFFFF).
+ *   [2048, 2560)     entries: b0 | b1 << 8 | b2 << 16 | unique-pattern id << 24; b2 = 0x00 for a 2-byte pattern
+ *                    (v_msad_u8 skips a 0x00 reference byte: it matches whatever follows).  The unique patterns are
+ *                    numbered short ones (2 or 3 bytes) first: id < n_short means the entry decides alone.
+ *   [2560, 6656)     filter over the first three text bytes, one BYTE (0x00 / 0xFF) per slot, 16384 slots: slot
+ *                    KMP_MULTI_SLOT(b0 | b1 << 8 | (b2 & 31) << 16) is 0xFF for every pattern of 3+ bytes, and for all 32
+ *                    values of b2 & 31 for a 2-byte pattern (so one lookup serves both).  A whole byte per slot because
+ *                    the kernel then needs no bit extraction: start offset i ANDs the byte with 1 << (i & 7) and ORs it
+ *                    into its hit mask in one v_and_or_b32.
+ *   [6656, ...)      one 4-word record per LONG unique pattern (4+ bytes; record = id - n_short): bytes 0-3, bytes 4-7,
+ *                    the byte mask of bytes 4-7, m | pattern index << 8 (a pattern of nine bytes or more compares its
+ *                    rest against kmp_pattern_dev[index].pat)
+ * The first 6656 words live in static LDS (their offsets fold into the ds_read offset field). */
 #define KMP_MULTI_BUCKETS     1024u
 #define KMP_MULTI_BUCKET_W0   0u
-#define KMP_MULTI_ENTRY_W0    512u
+#define KMP_MULTI_ENTRY_W0    2048u
 #define KMP_MULTI_MAX_ENTRIES 512u
-#define KMP_MULTI_FILTER_W0   1024u
-#define KMP_MULTI_REC_W0      3072u
-#define KMP_MULTI_REC_WORDS   12u
+#define KMP_MULTI_MAX_TWO     8u       /* 2-byte patterns a group may hold and still be bucketed by three bytes */
+#define KMP_MULTI_FILTER_W0   2560u
+#define KMP_MULTI_FILTER_SLOTS 16384u
+#define KMP_MULTI_REC_W0      (KMP_MULTI_FILTER_W0 + KMP_MULTI_FILTER_SLOTS / 4u)
+#define KMP_MULTI_REC_WORDS   4u
 #define KMP_MULTI_MAX_UNIQUE  256u
 #define KMP_MULTI_MIN_LEN     2u
-#define KMP_MULTI_PREFIX      20u      /* bytes of a pattern held in its record */
+#define KMP_MULTI_SHORT_LEN   3u       /* patterns up to this length are decided by their bucket entry alone */
 #define KMP_MULTI_MAX_LEN     99u
-#define KMP_MULTI_WIN_WORDS   (KMP_CHUNK / 4u + 28u)     /* per-wavefront LDS window: the chunk + 112 bytes of the next one */
-#define KMP_MULTI_BIT(w24)    ((((uint32_t)(w24) & 0xFFFFFFu) * 0x9E3779u) >> 16)   /* v_mul_u32_u24, 16-bit hash */
-#define KMP_MULTI_HASH(w16)   ((((uint32_t)(w16) * 0x9E3Bu) >> 6) & (KMP_MULTI_BUCKETS - 1u))
+#define KMP_MULTI_KEYMASK     0x1FFFFFu                  /* b0, b1 and the low five bits of b2 */
+#define KMP_MULTI_MUL         0x9E3779u
+#define KMP_MULTI_SLOT(w24)   ((uint32_t)(((uint32_t)(w24) & KMP_MULTI_KEYMASK) * KMP_MULTI_MUL) >> 18)      /* v_and + v_mul_u32_u24 + v_lshrrev */
+#define KMP_MULTI_HASH(key)   ((uint32_t)((uint32_t)(key) * KMP_MULTI_MUL) >> 22)                                           /* key already masked: v_mul_u32_u24 + v_lshrrev */
 
 #endif

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kmp_device.h"
 #include "kmp_launch.h"
@@ -18,31 +19,47 @@ namespace {
  *
  * Same streaming skeleton as kmp_scan_packed_kernel (buffer-load ring, packet-start bitmap, byte-
  * balanced plan).  Per chunk:
- *   - rem = payload bytes left from the lane's first byte (uniform loop over the packet starts of the
- *     chunk; lengths come by scalar loads, offsets are implied by the bitmap because the arena is packed);
- *   - level 1: the 3-byte window at each of the 16 start offsets is hashed into a 64 Kbit LDS filter "some
- *     pattern may start with these bytes" (2-byte patterns set all 256 third bytes) -> 16-bit hit mask per lane;
- *   - level 2, per start offset that has a hit in some lane: hash the 2 bytes to a bucket, walk the
- *     bucket's short list of patterns, compare up to 20 bytes dword-wise with byte masks (text from
- *     registers, pattern records from LDS), check window-in-payload and the strlen() rule, and bump
- *     the pattern's counter in LDS.  Counters go to partials[unique pattern][block] at the end.
+ *   - rem = payload bytes left from the lane's first byte (CLEAN: two lane masks off the start bitmap; otherwise a
+ *     uniform loop over the packet starts of the chunk with lengths by scalar loads);
+ *   - level 1: the 3-byte window at each of the 16 start offsets is hashed (v_and + v_mul_u32_u24 + v_lshrrev) into a
+ *     filter of 16384 one-byte slots in LDS, "some pattern may start with these bytes"; a whole byte per slot so that
+ *     start offset i needs no bit extraction: it ANDs the byte with 1 << (i & 7) and ORs it into its hit mask in one
+ *     instruction.  This level is bound by the LDS bank conflicts of its 16 random byte reads per lane, not by VALU
+ *     (profiles/r02_fused_ablation.txt);
+ *   - hits are not looked at here.  Every lane that has one appends ONE 32-byte record -- its 24 text bytes, its hit
+ *     mask, the room up to the payload's end, its position -- to the wavefront's queue in LDS (slot = mbcnt over the
+ *     ballot of those lanes: one ballot and two writes per chunk, no loop, no dependent LDS read), and whenever the
+ *     queue holds KMP_MULTI_QBATCH records
+ *   - level 2 takes them, ONE RECORD PER LANE, every lane busy: for each hit of its record (one, rarely two or three)
+ *     the lane cuts the eight text bytes behind the hit offset out of the record (select + v_alignbyte with a per-lane
+ *     shift); their first three bytes (five bits of the third) hash to a bucket {first entry, count}; an entry carries
+ *     the pattern's first three bytes and its id, v_msad_u8 compares them in one instruction (a 2-byte pattern has
+ *     0x00 as third byte, which the masked SAD skips).  Patterns of 2 or 3 bytes -- most matches in text -- are
+ *     decided right there; a longer one compares its first eight bytes, and only a pattern of nine bytes or more whose
+ *     first eight match reads the rest of the text from the arena itself.  Matches bump the pattern's counter in LDS;
+ *     counters go to partials[unique pattern][block].
+ *     (Round 1 walked every lane's hits chunk by chunk: 2 rounds of ~40 dependent instructions and three LDS round trips
+ *     with 7 % of the lanes doing work, 55 % of the kernel's time.)
  * ============================================================================================== */
+constexpr uint32_t QCAP = 96u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
+constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a time */
+
 template <int DEPTH, bool NT, bool CLEAN, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
-                      const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,
-                      unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
+                      const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
+                      uint32_t ablate, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
                       const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
-     * into the ds_read offset field; records, counters and one chunk window per wavefront follow dynamically */
+     * into the ds_read offset field; records, counters and one hit queue per wavefront follow dynamically */
     __shared__ __attribute__((aligned(16))) uint32_t s_fix[KMP_MULTI_REC_W0];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t rec_words = table_words - KMP_MULTI_REC_W0;
     uint32_t *s_rec = s_dyn;
     uint32_t *s_cnt = s_dyn + rec_words;
-    uint32_t *s_win = s_dyn + ((rec_words + n_unique + 3u) & ~3u);
+    uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 3u) & ~3u));
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
@@ -54,7 +71,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;
 
     /* The stream starts before the tables are copied: the first DEPTH chunk loads need nothing but the range, and
-     * filling 16-30 KB of LDS from global memory takes longer than they do (an empty range has a record count of
+     * filling 25-35 KB of LDS from global memory takes longer than they do (an empty range has a record count of
      * 0: its loads fetch nothing and return zeros). */
     const i32x4    rsrc = make_rsrc(arena + off0, range);
     const uint32_t vo0 = lane * KMP_LANE_BYTES;
@@ -66,9 +83,11 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
     for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
     __syncthreads();
-    const uint16_t *s_bucket = reinterpret_cast<const uint16_t *>(s_fix + KMP_MULTI_BUCKET_W0);
+    const uint32_t *s_bucket = s_fix + KMP_MULTI_BUCKET_W0;
     const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
     const uint8_t  *s_filter = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
+    uint4 *q = s_q + wave * (2u * QCAP);         /* this wavefront's queue: a ring of 32-byte records {24 text bytes, hit mask | room << 16, position} */
+    uint32_t q_head = 0u, q_count = 0u;          /* wave-uniform */
 
     if (range) {
         const uint64_t b0 = off0 >> 4;
@@ -85,6 +104,106 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
         int32_t  remc = 0;                   /* payload bytes of that packet left at the chunk's first byte     */
         bool     dead = false;
         uint32_t cb = 0u, j = 0u;
+        /* EMIT only: the start bits of the chunk whose hits are in the queue (the queue is emptied after every chunk there) */
+        uint64_t e_st = 0ull;
+
+        /* one match of unique pattern uid at stream position pos */
+        auto count_match = [&](uint32_t uid, uint32_t pos) {
+            atomicAdd(&s_cnt[uid], 1u);
+            if constexpr (EMIT) {
+                /* which packet, and how far into it: from the start bitmap of the chunk the hit lies in (the packet that
+                 * holds the hit's lane started at the highest start bit at or below that lane, or before the chunk) */
+                const uint32_t hl = (pos - cb) >> 4;
+                const uint64_t st_le = e_st & ((2ull << hl) - 1ull);
+                const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
+                const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
+                for (uint32_t u = uid_first[uid]; u < uid_first[uid + 1u]; ++u)      /* duplicates of a pattern are reported one by one */
+                    emit_match_as<true>(true, pkt, pos - pstart, uid_ids[u], em);
+            }
+        };
+        /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first} */
+        auto walk = [&](uint32_t T0, uint32_t T1, uint32_t room, uint32_t pos, uint2 bk, bool act) {
+            uint32_t ent = bk.x;
+            uint32_t e = bk.y & 0xFFFFu;
+            uint32_t n = act ? (bk.y >> 16) : 0u;                   /* entries left, this one included; a false hit of the filter usually finds an empty bucket */
+            while (ballot64(n != 0u) != 0ull) {
+                /* first three bytes (two for a 2-byte pattern: its third byte is 0x00 and skipped) */
+                const bool m3 = n != 0u && __builtin_amdgcn_msad_u8(T0, ent & 0x00FFFFFFu, 0u) == 0u;
+                const uint32_t uid = ent >> 24;
+                const bool lng = uid >= n_short;
+                bool hit = m3 && !lng && ((ent & 0x00FF0000u) ? 3u : 2u) <= room;
+                if (ballot64(m3 && lng) != 0ull) {
+                    /* rare: the first three bytes of a pattern of four bytes or more */
+                    if (m3 && lng) {
+                        const uint4 rec = *reinterpret_cast<const uint4 *>(s_rec + (uid - n_short) * KMP_MULTI_REC_WORDS);
+                        const uint32_t m = rec.w & 0xFFu;
+                        const bool eight = T0 == rec.x && ((T1 ^ rec.y) & rec.z) == 0u && m <= room;
+                        hit = eight && m <= 8u;
+                        if (eight && m > 8u) {
+                            /* rarer: nine bytes or more, the first eight match: the rest straight from the arena (a 0x00 of
+                             * the slot padding, or of the slack behind the last slot, ends the comparison) */
+                            bool ok = true;
+                            if constexpr (CLEAN) {
+                                /* room only tells 16 / 32 / more there: the exact distance to the next packet start */
+                                const uint64_t a = off0 + pos, b = (a >> 4) + 1ull;
+                                const unsigned long long w0 = bitmap[b >> 6], w1 = bitmap[(b >> 6) + 1ull];
+                                const uint32_t s6 = (uint32_t)(b & 63ull);
+                                const uint64_t bits = s6 ? ((w0 >> s6) | (w1 << (64u - s6))) : w0;
+                                if (bits != 0ull) ok = (uint64_t)m <= ((b + (uint64_t)__builtin_ctzll(bits)) << 4) - a;
+                            }
+                            if (ok) {
+                                const uint8_t *tp = arena + off0 + pos;
+                                const uint8_t *pp = patterns[rec.w >> 8].pat;
+                                for (uint32_t b = 8u; b < m; ++b)
+                                    if (tp[b] != pp[b]) { ok = false; break; }
+                            }
+                            hit = ok;
+                        }
+                    }
+                }
+                if (hit) count_match(uid, pos);
+                n -= n != 0u ? 1u : 0u;
+                if (ballot64(n != 0u) == 0ull) break;
+                ent = s_entry[e];                                   /* a bucket with more than one pattern */
+                ++e;
+            }
+        };
+        /* Level 2 on the `nproc` oldest queue records, one per lane; two hits of a record at a time (their bucket reads
+         * go out together: this stage waits for LDS round trips, not for instruction issue). */
+        auto process_batch = [&](uint32_t nproc) {
+            const uint32_t slot = (q_head + lane) % QCAP;
+            const uint4 r0 = q[2u * slot], r1 = q[2u * slot + 1u];
+            const uint32_t t[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};        /* the lane's 16 text bytes and the 8 behind them */
+            uint32_t hm = lane < nproc ? (r1.z & 0xFFFFu) : 0u;
+            const int32_t rem = (int32_t)(r1.z >> 16);                          /* payload bytes from the record's first text byte (clamped) */
+            const uint32_t pos0 = r1.w;                                          /* position of that byte in the wavefront's stream */
+            const uint2 *s_bucket2 = reinterpret_cast<const uint2 *>(s_bucket);
+            while (ballot64(hm != 0u) != 0ull) {
+                uint32_t T0[2], T1[2], ii[2];
+                bool act[2];
+                uint2 bk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(hm | 0x10000u);   /* 16 = no hit left in this record */
+                    act[h] = hm != 0u;
+                    hm &= hm - 1u;
+                    /* the eight text bytes behind offset i */
+                    const uint32_t q4 = i >> 2;
+                    const uint32_t x0 = q4 == 1u ? t[1] : q4 == 2u ? t[2] : q4 == 3u ? t[3] : t[0];
+                    const uint32_t x1 = q4 == 1u ? t[2] : q4 == 2u ? t[3] : q4 == 3u ? t[4] : t[1];
+                    const uint32_t x2 = q4 == 1u ? t[3] : q4 == 2u ? t[4] : q4 == 3u ? t[5] : t[2];
+                    T0[h] = __builtin_amdgcn_alignbyte(x1, x0, i);               /* shift = i & 3 bytes */
+                    T1[h] = __builtin_amdgcn_alignbyte(x2, x1, i);
+                    ii[h] = i;
+                    bk[h] = s_bucket2[(uint32_t)__umul24(T0[h] & bmask, KMP_MULTI_MUL) >> 22];      /* KMP_MULTI_HASH */
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    walk(T0[h], T1[h], (uint32_t)max(rem - (int32_t)ii[h], 0), pos0 + ii[h], bk[h], act[h]);
+            }
+            q_head = (q_head + nproc) % QCAP;
+            q_count -= nproc;
+        };
 
         while (cb < range) {
             /* packet-start words: use this group's, then ask for the next group's (see kmp_scan_packed_kernel) */
@@ -122,23 +241,27 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     if (zl == 0ull) { if (st != 0ull) dead = false; }
                     else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
 
-                    /* rem: payload bytes left from this lane's first byte */
-                    int32_t rem;
-                    uint64_t sg_all = 0ull, nx_all = 0ull;      /* CLEAN: start bits of this chunk (not cut at the range's end) and of the next */
-                    if constexpr (CLEAN) {
-                        /* Slot padding is all 0x00 (kmp_check_padding_kernel), so the payload's end can be replaced by
-                         * the slot's end: a window that reaches into the padding holds a 0x00 and matches nothing.
-                         * Only lanes within 2 x 16 bytes of the next packet start are constrained (patterns are at
-                         * most 20 bytes): two lane masks from the start bitmap, no payload lengths, no loop. */
+                    /* rem: payload bytes left from this lane's first byte; last_lanes: the lanes behind which a packet starts */
+                    int32_t rem = 0;
+                    uint64_t last_lanes;
+                    {
                         uint64_t nx;                                                /* start bits of the next chunk */
                         if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
                         else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
                         const uint64_t sg = st_[s];                                 /* not cut at the range's end: the next wavefront's first start ends our last slot */
-                        const bool next1 = __builtin_amdgcn_inverse_ballot_w64((sg >> 1) | (nx << 63));     /* lane + 1 starts a packet */
-                        const bool next2 = __builtin_amdgcn_inverse_ballot_w64((sg >> 2) | (nx << 62));     /* lane + 2 does            */
-                        rem = next1 ? 16 : next2 ? 32 : (1 << 20);
-                        sg_all = sg; nx_all = nx;
-                    } else {
+                        last_lanes = (sg >> 1) | (nx << 63);
+                        if constexpr (CLEAN) {
+                            /* Slot padding is all 0x00 (kmp_check_padding_kernel), so the payload's end can be replaced by
+                             * the slot's end: a window that reaches into the padding holds a 0x00 and matches nothing.
+                             * Only lanes within 2 x 16 bytes of the next packet start are constrained (the queue entry
+                             * carries 8 text bytes; longer patterns get their exact room in level 2): two lane masks from
+                             * the start bitmap, no payload lengths, no loop. */
+                            const bool next1 = __builtin_amdgcn_inverse_ballot_w64(last_lanes);                      /* lane + 1 starts a packet */
+                            const bool next2 = __builtin_amdgcn_inverse_ballot_w64((sg >> 2) | (nx << 62));         /* lane + 2 does            */
+                            rem = next1 ? 16 : next2 ? 32 : (1 << 20);
+                        }
+                    }
+                    if constexpr (!CLEAN) {
                         /* from the index: uniform loop over the packet starts of the chunk (<= 0: slot padding) */
                         rem = remc - (int32_t)vo0;
                         int32_t remn = remc - (int32_t)KMP_CHUNK;
@@ -152,95 +275,51 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                         remc = remn;
                     }
 
-                    /* level 1: which start offsets may begin some pattern (filter over the first three bytes)? */
-                    uint32_t hm = 0u;
+                    /* level 1: which start offsets may begin some pattern (filter over the first three bytes)?  Start offset
+                     * i takes plane i & 7 of its filter byte. */
+                    uint32_t hm = 0u, hm_hi = 0u;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q4 = 0; q4 < 4; ++q4) {
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
-                            const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q + 1], w[q], a) : w[q];
-                            const uint32_t pr = __umul24(d0, 0x9E3779u);                               /* KMP_MULTI_BIT = pr >> 16: hash of 3 text bytes */
-                            const uint32_t fb = s_filter[pr >> 19];
-                            hm |= __builtin_amdgcn_ubfe(fb, (pr >> 16) & 7u, 1u) << (4 * q + a);
+                            const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q4 + 1], w[q4], a) : w[q4];
+                            const uint32_t fb = s_filter[(uint32_t)__umul24(d0 & KMP_MULTI_KEYMASK, KMP_MULTI_MUL) >> 18];      /* KMP_MULTI_SLOT (the cast: __umul24 is typed int, the shift must be logical) */
+                            if (q4 < 2) hm    = (fb & (1u << ((4 * q4 + a) & 7))) | hm;
+                            else        hm_hi = (fb & (1u << ((4 * q4 + a) & 7))) | hm_hi;
                         }
                     }
+                    hm |= hm_hi << 8;
+                    if (ablate == 1u) hm = 0u;
                     if (ballot64(hm != 0u) != 0ull) {
-                        /* keep only the start offsets that can count: no 0x00 before them (strlen rule) and at
-                         * least the shortest pattern still inside the payload */
+                        /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
+                         * and no 0x00 before them (strlen rule, serial.c:191).  Nearly every 0x00 of real traffic and all of the
+                         * synthetic input's sit in the LAST lane of a packet (slot padding, trailers): those end nothing but
+                         * their own lane, and there only for a lane that has a hit -- the general, segmented form
+                         * (nul_limit) is kept for a 0x00 in mid-packet. */
                         int32_t lim = min(15, rem - (int32_t)KMP_MULTI_MIN_LEN);
-                        if (zl != 0ull || dead_in) lim = min(lim, nul_limit(15, w, zl, st, dead_in, lane));
+                        if (dead_in || (zl & ~last_lanes) != 0ull) lim = min(lim, nul_limit(15, w, zl, st, dead_in, lane));
+                        else if (ballot64(zm != 0u && hm != 0u) != 0ull) lim = min(lim, nul_limit(15, w, 0ull, st, false, lane));
                         hm = (lim < 0) ? 0u : (hm & ((2u << lim) - 1u));
-                        if (ballot64(hm != 0u) != 0ull) {
-                            /* level 2.  Stage the chunk + 32 bytes of halo in this wavefront's LDS window so that a
-                             * lane can fetch the 20 bytes behind ANY of its start offsets, then let every lane walk
-                             * its own hits: iterations = the largest hit count of a lane, not 16. */
-                            uint32_t *win = s_win + wave * KMP_MULTI_WIN_WORDS;
-                            *reinterpret_cast<uint4 *>(win + lane * 4u) = v;
-                            if (lane < 7u) *reinterpret_cast<uint4 *>(win + KMP_CHUNK / 4u + lane * 4u) = make_uint4(bn.x, bn.y, bn.z, bn.w);
-                            while (ballot64(hm != 0u) != 0ull) {
-                                if (hm != 0u) {
-                                    const uint32_t i = (uint32_t)__builtin_ctz(hm);
-                                    hm &= hm - 1u;
-                                    const uint32_t o = vo0 + i;                         /* byte offset inside the chunk window */
-                                    const uint32_t *src = win + (o >> 2);
-                                    const uint32_t sa = o & 3u;
-                                    const uint32_t r0 = src[0], r1 = src[1];
-                                    const uint32_t T0 = __builtin_amdgcn_alignbyte(r1, r0, sa);
-                                    const uint32_t b2 = (T0 >> 16) & 0xFFu;             /* third text byte: cheap pre-check per entry */
-                                    uint32_t e = s_bucket[(__umul24(T0, 0x9E3Bu) >> 6) & (KMP_MULTI_BUCKETS - 1u)];   /* KMP_MULTI_HASH: bits 6..15 see 2 bytes only */
-                                    while (e != 0xFFFFu) {
-                                        const uint32_t ent = s_entry[e];
-                                        const uint32_t pb2 = (ent >> 8) & 0xFFu;
-                                        if (pb2 == 0u || pb2 == b2) {
-                                            /* rare: fetch the other 16 text bytes and the pattern record */
-                                            const uint32_t uid = ent & 0xFFu;
-                                            const uint32_t *rec = s_rec + uid * KMP_MULTI_REC_WORDS;
-                                            uint32_t diff = (T0 ^ rec[0]) & rec[5];
-                                            uint32_t prev = r1;
-#pragma unroll
-                                            for (int d = 1; d < 5; ++d) {
-                                                const uint32_t nx = src[d + 1];
-                                                diff |= (__builtin_amdgcn_alignbyte(nx, prev, sa) ^ rec[d]) & rec[5 + d];
-                                                prev = nx;
-                                            }
-                                            bool hit = diff == 0u && (int32_t)(i + rec[10]) <= rem;
-                                            if (hit && (ent & 0x40000000u)) {
-                                                /* a pattern of more than 20 bytes whose first 20 matched: exact room up to the slot's end
-                                                 * (CLEAN: rem only tells 16 / 32 / more), then the remaining bytes, text from the LDS
-                                                 * window, pattern from its kmp_pattern_dev */
-                                                const uint32_t m = rec[10];
-                                                if constexpr (CLEAN) {
-                                                    const uint64_t above = (sg_all >> 1) >> lane;
-                                                    uint32_t d = 4096u;
-                                                    if (above != 0ull) d = (uint32_t)__builtin_ctzll(above) + 1u;
-                                                    else if (nx_all != 0ull) d = 64u - lane + (uint32_t)__builtin_ctzll(nx_all);
-                                                    hit = i + m <= d * KMP_LANE_BYTES;
-                                                }
-                                                if (hit) {
-                                                    const uint8_t *pp = patterns[rec[11] - 1u].pat;
-                                                    const uint8_t *tw = reinterpret_cast<const uint8_t *>(win) + o;
-                                                    for (uint32_t b = KMP_MULTI_PREFIX; b < m; ++b)
-                                                        if (tw[b] != pp[b]) { hit = false; break; }
-                                                }
-                                            }
-                                            if (hit) {
-                                                atomicAdd(&s_cnt[uid], 1u);
-                                                if constexpr (EMIT) {
-                                                    /* which packet, and how far into it: from the start bitmap (the packet that
-                                                     * holds this lane started at the highest start bit at or below the lane, or
-                                                     * before the chunk) */
-                                                    const uint64_t st_le = st & ((2ull << lane) - 1ull);
-                                                    const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
-                                                    const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
-                                                    const uint32_t offs = cb + o - pstart;
-                                                    for (uint32_t t = uid_first[uid]; t < uid_first[uid + 1u]; ++t)      /* duplicates of a pattern are reported one by one */
-                                                        emit_match_as<true>(true, pkt, offs, uid_ids[t], em);
-                                                }
-                                            }
-                                        }
-                                        e = (ent & 0x80000000u) ? 0xFFFFu : e + 1u;
-                                    }
-                                }
+                        if (ablate == 2u) hm = 0u;
+                        const uint64_t hl_ = ballot64(hm != 0u);                    /* the lanes that have a hit */
+                        if (hl_ != 0ull) {
+                            /* append one record per such lane to the queue */
+                            const uint32_t nnew = (uint32_t)__builtin_popcountll(hl_);
+                            if (q_count + nnew > QCAP) process_batch(min(q_count, 64u));     /* then at most 64 records stay */
+                            const uint32_t w5 = wave_shl1(v.y, sgpr(bn.y));        /* text bytes 20..23 from the lane's first: a hit near its end carries 8 bytes too */
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hl_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hl_, 0u));
+                            if (hm != 0u) {
+                                const uint32_t slot = (q_head + q_count + rank) % QCAP;
+                                q[2u * slot]      = v;
+                                q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), cb + vo0);
+                            }
+                            q_count += nnew;
+                            if (ablate == 3u) { q_head = 0u; q_count = 0u; }
+                            if constexpr (EMIT) {
+                                e_st = st;
+                                while (q_count != 0u) process_batch(min(q_count, 64u));
+                            } else {
+                                if (q_count >= QBATCH) process_batch(QBATCH);
                             }
                         }
                     }
@@ -257,6 +336,8 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                 ++j;
             }
         }
+        /* what is left in the queue */
+        while (q_count != 0u) process_batch(min(q_count, 64u));
     }
 #pragma unroll
     for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);     /* nothing in flight when the wavefront ends */
@@ -268,20 +349,27 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 
 }  // namespace
 
+/* LDS one block of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
+size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique)
+{
+    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * QCAP * 8u) * sizeof(uint32_t);
+}
+
 /* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
-hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique,
+hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st)
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
-    const size_t lds = ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * KMP_MULTI_WIN_WORDS) * sizeof(uint32_t);
+    const size_t lds = kmp_multi_lds_bytes(table_words, n_unique) - (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t);      /* the dynamic part */
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
+    const char *abl = getenv("KMP_MULTI_ABLATE");                  /* tuning only (tools/fused_ablation.py): 1 = level 1 alone, 2 = + hit masking, 3 = + queueing */
+    const uint32_t ablate = abl ? (uint32_t)atoi(abl) : 0u;
 #define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
-        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, a.partials, em, uid_first, uid_ids, a.patterns)
+        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, ablate, a.partials, em, uid_first, uid_ids, a.patterns)
     if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, false, true); }
     else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true, false); else KMP_MULTI_LAUNCH(false, true, false); }
     else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false, false); else KMP_MULTI_LAUNCH(false, false, false); }
 #undef KMP_MULTI_LAUNCH
     return hipGetLastError();
 }
-

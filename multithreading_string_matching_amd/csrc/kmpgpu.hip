@@ -77,7 +77,7 @@ struct kmpgpu_ctx {
         uint32_t *d_ids = nullptr;           /* [n_ids] pattern indices counted by this group            */
         uint32_t *d_rows = nullptr;          /* [n_ids] their unique-pattern row                         */
         uint32_t *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
-        uint32_t  words = 0, n_unique = 0, n_ids = 0;
+        uint32_t  words = 0, n_unique = 0, n_short = 0, bmask = 0, n_ids = 0;
     };
     std::vector<FusedGroup> fused_groups;
     uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
@@ -151,8 +151,16 @@ uint32_t grid_blocks(const kmpgpu_ctx *c)
      * the packed kernel (profiles/r01_packed_tuning.txt), 7 for the fused pass (latency-bound level 2; 7 blocks
      * of LDS fit a CU; profiles/r01_fused_blocks_per_cu.txt), 8 for the general one */
     const bool streaming = use_flat(c) || use_packed(c);
+    int fused_bpc = 7;
+    if (use_fused(c)) {
+        /* as many blocks as the CU's 160 KB of LDS hold (the grid is persistent: a block that cannot be resident would
+         * run as a second round), at most 7 */
+        size_t lds = 1;
+        for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) lds = std::max(lds, kmp_multi_lds_bytes(g.words, g.n_unique));
+        fused_bpc = (int)std::max<size_t>(1, std::min<size_t>(7, (160u * 1024u) / (lds + 512u)));
+    }
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
-                  : use_fused(c) ? 7 : !streaming ? 8 : use_flat(c) ? 4 : 6;
+                  : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
     if (streaming && c->blocks_per_cu <= 0) {
         /* small captures: give every wavefront at least 8 KiB to stream instead of launching
@@ -347,7 +355,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             f.partials = c->d_partials;
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
-            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.d_uid_first, g.d_uid_ids, c->stream));
+            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.d_uid_first, g.d_uid_ids, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate));
             ++nl;
@@ -565,41 +573,62 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     if (where.size() < 2) {                       /* nothing to fuse: every pattern keeps its own pass (c->d_ids) */
         return KMPGPU_OK;
     }
-    for (const HostGroup &h : hg) {
+    for (HostGroup &h : hg) {
         const uint32_t U = (uint32_t)h.uniq.size();
+        /* number the unique patterns short ones (2 or 3 bytes: decided by their bucket entry alone) first */
+        uint32_t n_short = 0;
+        {
+            std::vector<uint32_t> order, new_row(U);
+            for (uint32_t u = 0; u < U; u++) if (h.uniq[u].size() <= KMP_MULTI_SHORT_LEN) order.push_back(u);
+            n_short = (uint32_t)order.size();
+            for (uint32_t u = 0; u < U; u++) if (h.uniq[u].size() > KMP_MULTI_SHORT_LEN) order.push_back(u);
+            std::vector<std::string> uq(U);
+            for (uint32_t r = 0; r < U; r++) { uq[r] = h.uniq[order[r]]; new_row[order[r]] = r; }
+            h.uniq.swap(uq);
+            for (uint32_t &r : h.rows) r = new_row[r];
+        }
+        const uint32_t n_long = U - n_short;
         std::vector<uint32_t> where_first(U, UINT32_MAX);                         /* a pattern index for every row */
         for (size_t i = 0; i < h.ids.size(); i++) where_first[h.rows[i]] = std::min(where_first[h.rows[i]], h.ids[i]);
-        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)U * KMP_MULTI_REC_WORDS, 0u);
-        uint16_t *bucket = reinterpret_cast<uint16_t *>(tab.data() + KMP_MULTI_BUCKET_W0);
+        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)n_long * KMP_MULTI_REC_WORDS, 0u);
+        uint32_t *bucket = tab.data() + KMP_MULTI_BUCKET_W0;
         uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
         std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
+        uint32_t n_two = 0;
+        for (uint32_t u = 0; u < U; u++) n_two += h.uniq[u].size() == 2 ? 1u : 0u;
+        const uint32_t bmask = n_two <= KMP_MULTI_MAX_TWO ? KMP_MULTI_KEYMASK : 0xFFFFu;        /* bucket key: three bytes, or two when 2-byte patterns abound */
         for (uint32_t u = 0; u < U; u++) {
             const std::string &p = h.uniq[u];
             const uint32_t w16 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8);
-            for (uint32_t t = 0; t < 256u; t++) {                     /* a 2-byte pattern matches whatever follows it */
+            uint8_t *filter = reinterpret_cast<uint8_t *>(tab.data() + KMP_MULTI_FILTER_W0);
+            for (uint32_t t = 0; t < 32u; t++) {                      /* a 2-byte pattern matches whatever follows it */
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : t;
-                const uint32_t bi = KMP_MULTI_BIT(w16 | (third << 16));
-                tab[KMP_MULTI_FILTER_W0 + (bi >> 5)] |= 1u << (bi & 31u);
+                const uint32_t w24 = w16 | (third << 16);
+                filter[KMP_MULTI_SLOT(w24)] = 0xFFu;
+                std::vector<uint32_t> &l = lists[KMP_MULTI_HASH(w24 & bmask)];
+                if (l.empty() || l.back() != u) l.push_back(u);
                 if (p.size() >= 3) break;
             }
-            lists[KMP_MULTI_HASH(w16)].push_back(u);
-            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)u * KMP_MULTI_REC_WORDS;
-            for (uint32_t b = 0; b < p.size() && b < KMP_MULTI_PREFIX; b++) {
+            if (u < n_short) continue;
+            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)(u - n_short) * KMP_MULTI_REC_WORDS;
+            for (uint32_t b = 0; b < p.size() && b < 8u; b++) {
                 rec[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
-                rec[5 + (b >> 2)] |= 0xFFu << (8 * (b & 3));
+                if (b >= 4u) rec[2] |= 0xFFu << (8 * (b & 3));
             }
-            rec[10] = (uint32_t)p.size();
-            if (p.size() > KMP_MULTI_PREFIX) rec[11] = where_first[u] + 1u;       /* the rest of it: kmp_pattern_dev[that index].pat */
+            rec[3] = (uint32_t)p.size() | (where_first[u] << 8);       /* the rest of it: kmp_pattern_dev[that index].pat */
         }
         uint32_t pos = 0;
         for (uint32_t hh = 0; hh < KMP_MULTI_BUCKETS; hh++) {
-            if (lists[hh].empty()) { bucket[hh] = 0xFFFFu; continue; }
-            bucket[hh] = (uint16_t)pos;
             for (size_t q = 0; q < lists[hh].size(); q++) {
                 const std::string &p = h.uniq[lists[hh][q]];
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : 0u;      /* never 0x00 inside a pattern */
-                entry[pos++] = lists[hh][q] | (third << 8) | (p.size() > KMP_MULTI_PREFIX ? 0x40000000u : 0u) | (q + 1 == lists[hh].size() ? 0x80000000u : 0u);
+                const uint32_t ent = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | (third << 16) | (lists[hh][q] << 24);
+                if (q == 0) { bucket[2 * hh] = ent; continue; }       /* the first entry sits in the bucket itself */
+                if (pos >= KMP_MULTI_MAX_ENTRIES) return fail(KMPGPU_EINVAL, "kmpgpu_set_patterns: fused tables: entry list overflow");
+                entry[pos++] = ent;
             }
+            const uint32_t extra = lists[hh].empty() ? 0u : (uint32_t)lists[hh].size() - 1u;
+            bucket[2 * hh + 1] = (pos - extra) | ((uint32_t)lists[hh].size() << 16);
         }
         /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) */
         std::vector<uint32_t> uid_first(U + 1, 0u), uid_ids(h.ids.size());
@@ -619,7 +648,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         HIP_TRY(up(&g.d_rows, h.rows));
         HIP_TRY(up(&g.d_uid_first, uid_first));
         HIP_TRY(up(&g.d_uid_ids, uid_ids));
-        g.words = (uint32_t)tab.size(); g.n_unique = U; g.n_ids = (uint32_t)h.ids.size();
+        g.words = (uint32_t)tab.size(); g.n_unique = U; g.n_short = n_short; g.bmask = bmask; g.n_ids = (uint32_t)h.ids.size();
         c->n_multi_unique += U;
     }
     std::vector<uint32_t> rest(rest_l);

@@ -1,0 +1,26 @@
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import multithreading_string_matching_amd as K
+from multithreading_string_matching_amd.matcher import GpuMatcher, OPT_FUSED, OPT_BLOCKS_PER_CU
+pats = K.load_patterns("tests/golden/data/strings.txt")
+m = GpuMatcher(0)
+n, L = 1_000_000, 1500
+sp = K.SynthParams.make(seed=1234, needle=b"NEEDLE_16B_PATRN", plant_permille=100)
+d_arena = torch.zeros(n * 1504 + 64, dtype=torch.uint8, device="cuda")
+d_off = torch.empty(n, dtype=torch.int64, device="cuda"); d_len = torch.empty(n, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize(); m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_arena, d_off, d_len, sp); m.sync()
+m.set_option(OPT_FUSED, 1)
+for name, pp in (("97", pats), ("3+ bytes only", [p for p in pats if len(p) >= 3]), ("4+ bytes only", [p for p in pats if len(p) >= 4])):
+    m.set_patterns(pp); m.attach_arena(d_arena, d_off, d_len)
+    for bpc in (0, 4, 5, 7):
+        m.set_option(OPT_BLOCKS_PER_CU, bpc)
+        for _ in range(20): m.scan_enqueue()
+        m.sync()
+        N = 40
+        m.profile_begin(N)
+        for _ in range(N): m.scan_enqueue()
+        ms = m.profile_end(N)
+        c = m.scan()[0]
+        print(f"ablate={os.environ.get('KMP_MULTI_ABLATE','0')} {name:14s} bpc={bpc}: {ms.mean()*1e3:7.1f} us  sum {int(c.sum())}", flush=True)
+m.close()
