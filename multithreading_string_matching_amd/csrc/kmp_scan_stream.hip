@@ -119,7 +119,14 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
                          * window inside the payload, no 0x00 before it, lane has a candidate at all. */
                         int32_t maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
                         if (fz == 0u) maxi = -1;
-                        if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                        if (zl != 0ull || dead_in) {
+                            /* A 0x00 in the LAST lane of a packet (slot padding, a trailer) ends nothing but that lane's own
+                             * later offsets -- and matters only if that lane has a candidate; the segmented form is for a
+                             * 0x00 in mid-packet. */
+                            const uint64_t last_lanes = ballot64(p0 + KMP_LANE_BYTES == stride);
+                            if (dead_in || (zl & ~last_lanes) != 0ull) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                            else if (ballot64(zm != 0u && fz != 0u) != 0ull) maxi = nul_limit(maxi, w, 0ull, st, false, lane);
+                        }
                         const uint64_t pkt = EMIT ? (k0 + (uint64_t)((cb + vo0 - p0) / stride)) : 0ull;
                         confirm_sad<EMIT>(S, t, w, v, bn, fz, maxi, p0, pc, gp, cnt, pkt, em);
                     }
@@ -288,6 +295,9 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                         int32_t  maxi = -1;
                         uint32_t p0 = 0u, L = 0u;
                         uint64_t kl = 0ull;
+                        uint64_t nx;                                                    /* start bits of the next chunk */
+                        if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
+                        else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
                         if (!EMIT && pad_clean) {
                             /* Slot padding is all 0x00 (checked when the arena was loaded), so "the window lies inside
                              * the payload" = "it lies inside the slot and holds no 0x00": the distance to the next
@@ -297,12 +307,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                                 const uint64_t above = (st >> 1) >> lane;               /* starts at the lanes above own */
                                 uint32_t d = 4096u;                                     /* 16-byte groups up to the next start */
                                 if (above != 0ull) d = (uint32_t)__builtin_ctzll(above) + 1u;
-                                else {
-                                    uint64_t nx;                                        /* start bits of the next chunk */
-                                    if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
-                                    else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
-                                    if (nx != 0ull) d = 64u - lane + (uint32_t)__builtin_ctzll(nx);
-                                }
+                                else if (nx != 0ull) d = 64u - lane + (uint32_t)__builtin_ctzll(nx);
                                 L = d * KMP_LANE_BYTES;                                 /* bytes from the lane's first to the slot's end */
                                 maxi = (int32_t)L - (int32_t)m;
                             }
@@ -314,7 +319,12 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                             p0 = (uint32_t)(off0 + cb + vo0 - po);
                             maxi = (int32_t)L - (int32_t)m - (int32_t)p0;
                         }
-                        if (zl != 0ull || dead_in) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                        if (zl != 0ull || dead_in) {
+                            /* a 0x00 in the last lane of a packet ends nothing but that lane's own later offsets (see kmp_scan_flat_kernel) */
+                            const uint64_t last_lanes = (st >> 1) | (nx << 63);
+                            if (dead_in || (zl & ~last_lanes) != 0ull) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
+                            else if (ballot64(zm != 0u && fz != 0u) != 0ull) maxi = nul_limit(maxi, w, 0ull, st, false, lane);
+                        }
                         confirm_sad<EMIT>(S, t, w, v, bn, fz, maxi, p0, pc, gp, cnt, kl, em);
                         /* leave nothing of the rare path's LDS/scalar reads "possibly in flight": merged into the
                          * common path that state costs an s_waitcnt lgkmcnt(0) per chunk, which would also wait

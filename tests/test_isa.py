@@ -93,4 +93,4 @@ def test_fused_kernel_ring_is_unrolled(multi):
     for name, k in multi.items():
         assert _ring_waits(k["body"], 2) == 4, name
         assert _issues(k["body"]) == 8, name
-        assert k["occupancy"] >= 5, (name, k["vgprs"])              # 4 blocks of LDS (16 KB filter + tables + queues each) fit a CU
+        assert k["occupancy"] >= 4, (name, k["vgprs"])              # 4 blocks of LDS (16 KB filter + tables + queues each) fit a CU: 4 wavefronts per SIMD

@@ -1,3 +1,4 @@
+"""Tuning only: the fused multi-pattern pass cut after each of its stages (KMP_MULTI_ABLATE=1..3), strings.txt and its 3+ / 4+ byte subsets, blocks per CU."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
