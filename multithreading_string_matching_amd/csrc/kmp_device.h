@@ -50,6 +50,7 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_BUCKET_W0   0u
 #define KMP_MULTI_ENTRY_W0    2048u
 #define KMP_MULTI_MAX_ENTRIES 512u
+#define KMP_MULTI_MAX_ONES    4u       /* distinct 1-byte patterns the first group counts on the side */
 #define KMP_MULTI_MAX_TWO     8u       /* 2-byte patterns a group may hold and still be bucketed by three bytes */
 #define KMP_MULTI_FILTER_W0   2560u
 #define KMP_MULTI_FILTER_SLOTS 16384u

@@ -44,12 +44,12 @@ namespace {
 constexpr uint32_t QCAP = 96u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
 constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a time */
 
-template <int DEPTH, bool NT, bool CLEAN, bool EMIT = false>
+template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
-                      uint32_t ablate, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
+                      uint32_t n_ones, uint32_t ones, uint32_t ablate, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
                       const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
@@ -88,6 +88,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     const uint8_t  *s_filter = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
     uint4 *q = s_q + wave * (2u * QCAP);         /* this wavefront's queue: a ring of 32-byte records {24 text bytes, hit mask | room << 16, position} */
     uint32_t q_head = 0u, q_count = 0u;          /* wave-uniform */
+    uint32_t one_cnt[KMP_MULTI_MAX_ONES] = {0u, 0u, 0u, 0u};      /* this lane's matches of the 1-byte patterns that ride along */
 
     if (range) {
         const uint64_t b0 = off0 >> 4;
@@ -290,15 +291,54 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     }
                     hm |= hm_hi << 8;
                     if (ablate == 1u) hm = 0u;
-                    if (ballot64(hm != 0u) != 0ull) {
+                    if (ONES || ballot64(hm != 0u) != 0ull) {
                         /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
                          * and no 0x00 before them (strlen rule, serial.c:191).  Nearly every 0x00 of real traffic and all of the
                          * synthetic input's sit in the LAST lane of a packet (slot padding, trailers): those end nothing but
                          * their own lane, and there only for a lane that has a hit -- the general, segmented form
                          * (nul_limit) is kept for a 0x00 in mid-packet. */
-                        int32_t lim = min(15, rem - (int32_t)KMP_MULTI_MIN_LEN);
-                        if (dead_in || (zl & ~last_lanes) != 0ull) lim = min(lim, nul_limit(15, w, zl, st, dead_in, lane));
-                        else if (ballot64(zm != 0u && hm != 0u) != 0ull) lim = min(lim, nul_limit(15, w, 0ull, st, false, lane));
+                        int32_t nl = 15;                                             /* last start offset no 0x00 precedes */
+                        if (dead_in || (zl & ~last_lanes) != 0ull) nl = nul_limit(15, w, zl, st, dead_in, lane);
+                        else if (ballot64(zm != 0u && (ONES || hm != 0u)) != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);
+                        const int32_t lim = min(nl, rem - (int32_t)KMP_MULTI_MIN_LEN);
+                        if constexpr (ONES) {
+                            /* the 1-byte patterns: their byte against all 16 start offsets (v_mqsad with a one-byte reference),
+                             * counted where the offset lies inside the payload and before any 0x00 */
+                            const int32_t lim1 = min(nl, rem - 1);
+                            const bool barred = ballot64(lim1 < 15) != 0ull;
+                            const uint32_t nv = (uint32_t)min(max(lim1 + 1, 0), 16);
+                            const uint32_t nv2 = nv | (nv << 16);
+#pragma unroll
+                            for (uint32_t k = 0; k < KMP_MULTI_MAX_ONES; ++k) {
+                                if (k >= n_ones) break;
+                                const uint32_t ref = (ones >> (8u * k)) & 0xFFu;
+                                uint32_t found = 0u;
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    const uint64_t S = mqsad(w[q4], w[q4 + 1], ref, 0ull);
+                                    if constexpr (!EMIT) {
+                                        Emitter none{};
+                                        uint32_t dummy = 0u;
+                                        found = tally_group<false>(q4, S, barred, nv2, found, 0u, dummy, 0ull, none);
+                                    } else {
+#pragma unroll
+                                        for (int a = 0; a < 4; ++a) {
+                                            const bool ok = ((S >> (16 * a)) & 0xFFFFull) == 0ull && (4 * q4 + a) <= lim1;
+                                            one_cnt[k] += ok ? 1u : 0u;
+                                            if (ballot64(ok) != 0ull) {
+                                                const uint64_t st_le = st & ((2ull << lane) - 1ull);
+                                                const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
+                                                const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
+                                                const uint32_t row = n_unique - n_ones + k;
+                                                for (uint32_t u = uid_first[row]; u < uid_first[row + 1u]; ++u)
+                                                    emit_match_as<true>(ok, pkt, cb + vo0 + (uint32_t)(4 * q4 + a) - pstart, uid_ids[u], em);
+                                            }
+                                        }
+                                    }
+                                }
+                                if constexpr (!EMIT) one_cnt[k] += (found & 0xFFFFu) + (found >> 16);
+                            }
+                        }
                         hm = (lim < 0) ? 0u : (hm & ((2u << lim) - 1u));
                         if (ablate == 2u) hm = 0u;
                         const uint64_t hl_ = ballot64(hm != 0u);                    /* the lanes that have a hit */
@@ -342,6 +382,14 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 #pragma unroll
     for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);     /* nothing in flight when the wavefront ends */
 
+#pragma unroll
+    for (uint32_t k = 0; k < (ONES ? KMP_MULTI_MAX_ONES : 0u); ++k) {
+        if (k >= n_ones) break;
+        uint32_t c = one_cnt[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0u) atomicAdd(&s_cnt[n_unique - n_ones + k], c);
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS)
         partials[(uint64_t)i * gridDim.x + blockIdx.x] = s_cnt[i];
@@ -356,7 +404,7 @@ size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique)
 }
 
 /* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
-hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask,
+hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st)
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
@@ -365,11 +413,13 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
     const char *abl = getenv("KMP_MULTI_ABLATE");                  /* tuning only (tools/fused_ablation.py): 1 = level 1 alone, 2 = + hit masking, 3 = + queueing */
     const uint32_t ablate = abl ? (uint32_t)atoi(abl) : 0u;
-#define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
-        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, ablate, a.partials, em, uid_first, uid_ids, a.patterns)
+#define KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, ONES_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_, ONES_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
+        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.partials, em, uid_first, uid_ids, a.patterns)
+#define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) do { if (n_ones) KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, true); else KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, false); } while (0)
     if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, false, true); }
     else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true, false); else KMP_MULTI_LAUNCH(false, true, false); }
     else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false, false); else KMP_MULTI_LAUNCH(false, false, false); }
 #undef KMP_MULTI_LAUNCH
+#undef KMP_MULTI_LAUNCH1
     return hipGetLastError();
 }

@@ -77,7 +77,7 @@ struct kmpgpu_ctx {
         uint32_t *d_ids = nullptr;           /* [n_ids] pattern indices counted by this group            */
         uint32_t *d_rows = nullptr;          /* [n_ids] their unique-pattern row                         */
         uint32_t *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
-        uint32_t  words = 0, n_unique = 0, n_short = 0, bmask = 0, n_ids = 0;
+        uint32_t  words = 0, n_unique = 0, n_short = 0, bmask = 0, n_ones = 0, ones = 0, n_ids = 0;
     };
     std::vector<FusedGroup> fused_groups;
     uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
@@ -355,7 +355,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             f.partials = c->d_partials;
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
-            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.d_uid_first, g.d_uid_ids, c->stream));
+            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate));
             ++nl;
@@ -557,8 +557,18 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     std::vector<HostGroup> hg;
     std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> where;        /* pattern -> (group, row) */
     std::vector<uint32_t> rest_l, rest_s;
+    /* 1-byte patterns: up to KMP_MULTI_MAX_ONES distinct ones ride along with the first fused group (counted straight
+     * off the text registers, no filter, no queue); further ones keep one streaming pass each */
+    std::vector<uint8_t> one_bytes;
+    std::vector<std::pair<uint32_t, uint32_t>> one_ids;            /* (pattern index, slot) */
     for (uint32_t i = 0; i < n_pat; i++) {
         const uint32_t m = pat_len[i];
+        if (m == 1) {
+            size_t k = 0;
+            while (k < one_bytes.size() && one_bytes[k] != pat[i][0]) k++;
+            if (k == one_bytes.size() && k < KMP_MULTI_MAX_ONES) one_bytes.push_back(pat[i][0]);
+            if (k < one_bytes.size()) { one_ids.emplace_back(i, (uint32_t)k); continue; }
+        }
         if (m < KMP_MULTI_MIN_LEN || m > KMP_MULTI_MAX_LEN) { (m >= 4 ? rest_l : rest_s).push_back(i); continue; }
         const std::string key((const char *)pat[i], m);
         auto it = where.find(key);
@@ -573,8 +583,13 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     if (where.size() < 2) {                       /* nothing to fuse: every pattern keeps its own pass (c->d_ids) */
         return KMPGPU_OK;
     }
+    bool first_group = true;
     for (HostGroup &h : hg) {
         const uint32_t U = (uint32_t)h.uniq.size();
+        const uint32_t n_ones = first_group ? (uint32_t)one_bytes.size() : 0u;
+        uint32_t ones = 0;
+        for (uint32_t k = 0; k < n_ones; k++) ones |= (uint32_t)one_bytes[k] << (8 * k);
+        first_group = false;
         /* number the unique patterns short ones (2 or 3 bytes: decided by their bucket entry alone) first */
         uint32_t n_short = 0;
         {
@@ -630,10 +645,13 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             const uint32_t extra = lists[hh].empty() ? 0u : (uint32_t)lists[hh].size() - 1u;
             bucket[2 * hh + 1] = (pos - extra) | ((uint32_t)lists[hh].size() << 16);
         }
+        /* the 1-byte patterns that ride along: rows U .. U + n_ones - 1 */
+        if (n_ones)
+            for (const auto &oi : one_ids) { h.ids.push_back(oi.first); h.rows.push_back(U + oi.second); }
         /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) */
-        std::vector<uint32_t> uid_first(U + 1, 0u), uid_ids(h.ids.size());
+        std::vector<uint32_t> uid_first(U + n_ones + 1, 0u), uid_ids(h.ids.size());
         for (uint32_t r : h.rows) uid_first[r + 1]++;
-        for (uint32_t u = 0; u < U; u++) uid_first[u + 1] += uid_first[u];
+        for (uint32_t u = 0; u < U + n_ones; u++) uid_first[u + 1] += uid_first[u];
         { std::vector<uint32_t> fill(uid_first.begin(), uid_first.end() - 1);
           for (size_t i = 0; i < h.ids.size(); i++) uid_ids[fill[h.rows[i]]++] = h.ids[i]; }
         c->fused_groups.emplace_back();
@@ -648,7 +666,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         HIP_TRY(up(&g.d_rows, h.rows));
         HIP_TRY(up(&g.d_uid_first, uid_first));
         HIP_TRY(up(&g.d_uid_ids, uid_ids));
-        g.words = (uint32_t)tab.size(); g.n_unique = U; g.n_short = n_short; g.bmask = bmask; g.n_ids = (uint32_t)h.ids.size();
+        g.words = (uint32_t)tab.size(); g.n_unique = U + n_ones; g.n_short = n_short; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
         c->n_multi_unique += U;
     }
     std::vector<uint32_t> rest(rest_l);

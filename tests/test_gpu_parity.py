@@ -1183,3 +1183,36 @@ def test_borrowed_arena_must_be_reattached_after_a_rewrite(gm, oracle):
             gm.set_option(OPT_FUSED, 1 if kernel == KERNEL_FUSED else 0)
             assert gm.scan()[0].tolist() == want.tolist()
         gm.set_option(OPT_FUSED, 2)
+
+
+def test_fused_pass_counts_one_byte_patterns_on_the_side(gm, oracle):
+    """1-byte patterns (fscanf("%s") admits them, serial.c:66) ride along with the fused pass: up to four distinct ones are
+    counted in the same read of the arena, a fifth keeps its own pass; duplicates share a row; the strlen rule and the
+    payload end apply to them like to any pattern; offsets are reported too."""
+    rng = random.Random(31)
+    payloads = []
+    for k in range(500):
+        L = rng.randrange(0, 400)
+        b = bytearray(rng.choice(b"abcde") for _ in range(L))
+        if L and rng.random() < 0.4:
+            b[rng.randrange(L)] = 0
+        payloads.append(bytes(b))
+    pats = [b"a", b"ab", b"b", b"abc", b"c", b"a", b"d", b"e", b"deadbeef", b"ea"]
+    arena = K.HostArena.from_payloads(payloads)
+    want, _ = oracle.count(arena.bytes, arena.off, arena.len, pats)
+    assert want[0] == want[5] and want[0] > 0
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    gm.load_arena(arena)
+    for fused in (1, 2, 0):
+        gm.set_option(OPT_FUSED, fused)
+        got, t = gm.scan()
+        assert got.tolist() == want.tolist(), fused
+        if fused:
+            assert t.launches == 2                  # the fused pass + one streaming pass for the fifth 1-byte pattern
+    gm.set_option(OPT_FUSED, 1)
+    recs, found, counts = gm.scan_offsets(int(want.sum()) + 8)
+    assert found == int(want.sum()) and counts.tolist() == want.tolist()
+    assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in recs) == _expected_matches(payloads, pats)
+    gm.set_option(OPT_FUSED, 2)

@@ -52,7 +52,7 @@ def _issues(body):
 
 
 def test_no_spills_no_dynamic_register_indexing(stream, multi):
-    assert len(stream) >= 20 and len(multi) >= 6
+    assert len(stream) >= 20 and len(multi) >= 12
     for name, k in list(stream.items()) + list(multi.items()):
         assert k["scratch"] == 0, name
         assert "movrel" not in k["body"], name                     # a ring slot reached through a run-time index
