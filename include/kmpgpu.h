@@ -195,7 +195,9 @@ int  kmpgpu_profile_end(kmpgpu_ctx *ctx, float *ms_out, uint32_t *n);
 
 /* Counts plus the matches themselves: every (packet, start offset, pattern) that counts, at most
  * cap of them written to out (host memory, unspecified order); *n_found is the total number found
- * (may exceed cap).  Needs an arena whose slots are back to back, as kmp_arena builds them. */
+ * (may exceed cap).  The pass writes its counts to a buffer of its own: the context's counters (a running total under
+ * KMPGPU_OPT_ACCUMULATE, the result of a count reduce) stay as they are.  An arena that is scanned in place with slots
+ * not back to back (KMPGPU_OPT_REPACK = 0) is packed on this call, once. */
 int  kmpgpu_scan_offsets(kmpgpu_ctx *ctx, kmpgpu_match *out, uint64_t cap, uint64_t *n_found,
                          uint64_t *counts_out);
 

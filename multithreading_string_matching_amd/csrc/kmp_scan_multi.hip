@@ -169,41 +169,40 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                 ++e;
             }
         };
-        /* Level 2 on the `nproc` oldest queue records, one per lane; two hits of a record at a time (their bucket reads
-         * go out together: this stage waits for LDS round trips, not for instruction issue). */
+        /* Level 2 on the `nproc` oldest queue records, one per lane, ONE hit each: the rare record that holds another hit
+         * (one in nine) goes back to the end of the queue with that hit left in its mask, so every round of this stage
+         * runs with all its lanes busy instead of looping for the few records that need it. */
         auto process_batch = [&](uint32_t nproc) {
             const uint32_t slot = (q_head + lane) % QCAP;
             const uint4 r0 = q[2u * slot], r1 = q[2u * slot + 1u];
             const uint32_t t[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};        /* the lane's 16 text bytes and the 8 behind them */
-            uint32_t hm = lane < nproc ? (r1.z & 0xFFFFu) : 0u;
-            const int32_t rem = (int32_t)(r1.z >> 16);                          /* payload bytes from the record's first text byte (clamped) */
-            const uint32_t pos0 = r1.w;                                          /* position of that byte in the wavefront's stream */
-            const uint2 *s_bucket2 = reinterpret_cast<const uint2 *>(s_bucket);
-            while (ballot64(hm != 0u) != 0ull) {
-                uint32_t T0[2], T1[2], ii[2];
-                bool act[2];
-                uint2 bk[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(hm | 0x10000u);   /* 16 = no hit left in this record */
-                    act[h] = hm != 0u;
-                    hm &= hm - 1u;
-                    /* the eight text bytes behind offset i */
-                    const uint32_t q4 = i >> 2;
-                    const uint32_t x0 = q4 == 1u ? t[1] : q4 == 2u ? t[2] : q4 == 3u ? t[3] : t[0];
-                    const uint32_t x1 = q4 == 1u ? t[2] : q4 == 2u ? t[3] : q4 == 3u ? t[4] : t[1];
-                    const uint32_t x2 = q4 == 1u ? t[3] : q4 == 2u ? t[4] : q4 == 3u ? t[5] : t[2];
-                    T0[h] = __builtin_amdgcn_alignbyte(x1, x0, i);               /* shift = i & 3 bytes */
-                    T1[h] = __builtin_amdgcn_alignbyte(x2, x1, i);
-                    ii[h] = i;
-                    bk[h] = s_bucket2[(uint32_t)__umul24(T0[h] & bmask, KMP_MULTI_MUL) >> 22];      /* KMP_MULTI_HASH */
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    walk(T0[h], T1[h], (uint32_t)max(rem - (int32_t)ii[h], 0), pos0 + ii[h], bk[h], act[h]);
-            }
+            const bool act = lane < nproc;
+            const uint32_t hm = act ? (r1.z & 0xFFFFu) : 0u;
+            const uint32_t rem = r1.z >> 16;                                     /* payload bytes from the record's first text byte (clamped) */
+            const uint32_t i = (uint32_t)__builtin_ctz(hm | 0x10000u);
+            const uint32_t rest = hm & (hm - 1u);
+            /* the eight text bytes behind offset i */
+            const uint32_t q4 = i >> 2;
+            const uint32_t x0 = q4 == 1u ? t[1] : q4 == 2u ? t[2] : q4 == 3u ? t[3] : t[0];
+            const uint32_t x1 = q4 == 1u ? t[2] : q4 == 2u ? t[3] : q4 == 3u ? t[4] : t[1];
+            const uint32_t x2 = q4 == 1u ? t[3] : q4 == 2u ? t[4] : q4 == 3u ? t[5] : t[2];
+            const uint32_t T0 = __builtin_amdgcn_alignbyte(x1, x0, i);             /* shift = i & 3 bytes */
+            const uint32_t T1 = __builtin_amdgcn_alignbyte(x2, x1, i);
+            const uint2 bk = reinterpret_cast<const uint2 *>(s_bucket)[(uint32_t)__umul24(T0 & bmask, KMP_MULTI_MUL) >> 22];      /* KMP_MULTI_HASH */
             q_head = (q_head + nproc) % QCAP;
             q_count -= nproc;
+            const uint64_t again = ballot64(rest != 0u);
+            if (again != 0ull) {
+                /* at most `nproc` (<= 64) records come back; QCAP - 64 stayed at most */
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
+                if (rest != 0u) {
+                    const uint32_t s2 = (q_head + q_count + rank) % QCAP;
+                    q[2u * s2]      = r0;
+                    q[2u * s2 + 1u] = make_uint4(r1.x, r1.y, rest | (rem << 16), r1.w);
+                }
+                q_count += (uint32_t)__builtin_popcountll(again);
+            }
+            walk(T0, T1, rem > i ? rem - i : 0u, r1.w + i, bk, act);
         };
 
         while (cb < range) {
@@ -345,7 +344,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                         if (hl_ != 0ull) {
                             /* append one record per such lane to the queue */
                             const uint32_t nnew = (uint32_t)__builtin_popcountll(hl_);
-                            if (q_count + nnew > QCAP) process_batch(min(q_count, 64u));     /* then at most 64 records stay */
+                            while (q_count + nnew > QCAP) process_batch(min(q_count, 64u));  /* every batch resolves one hit per record: it ends */
                             const uint32_t w5 = wave_shl1(v.y, sgpr(bn.y));        /* text bytes 20..23 from the lane's first: a hit near its end carries 8 bytes too */
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hl_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hl_, 0u));
                             if (hm != 0u) {
@@ -359,7 +358,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                 e_st = st;
                                 while (q_count != 0u) process_batch(min(q_count, 64u));
                             } else {
-                                if (q_count >= QBATCH) process_batch(QBATCH);
+                                while (q_count >= QBATCH) process_batch(QBATCH);
                             }
                         }
                     }

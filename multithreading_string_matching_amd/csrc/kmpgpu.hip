@@ -377,7 +377,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
             if (emit && !flat && !packed)
-                return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets needs an arena whose slots are back to back (as kmp_arena builds them)");
+                return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: the arena could not be brought into the streaming kernels' layout");
             HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream, nullptr, c->accumulate));
@@ -988,6 +988,16 @@ int kmpgpu_scan_offsets(kmpgpu_ctx *c, kmpgpu_match *out, uint64_t cap, uint64_t
     static_assert(sizeof(kmpgpu_match) == 16, "kmpgpu_match is a 16-byte record");
     HIP_TRY(hipSetDevice(c->device));
     *n_found = 0;
+    if (!c->packed && c->n_pkts) {
+        /* an arena kept in place (KMPGPU_OPT_REPACK = 0) whose slots are not back to back: the offsets come from the
+         * streaming kernels, so it is packed now, once (the context scans its packed copy from here on) */
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int keep = c->repack;
+        c->repack = 1;
+        const int rr = prepare_packed(c);
+        c->repack = keep;
+        if (rr) return rr;
+    }
     void *d_out = nullptr;
     unsigned long long *d_cnt = nullptr;             /* [0] matches found; [1 ..] this pass's counts */
     const size_t np = c->n_pat ? c->n_pat : 1;

@@ -450,6 +450,12 @@ def test_non_packed_arena(gm, oracle):
                 assert a2[int(off2[k]):int(off2[k]) + int(ln2[k])].tobytes() == payloads[k]
         else:
             assert off2.tolist() == off.tolist()
+            # offsets from an arena kept in place: kmpgpu_scan_offsets packs it on demand (it used to refuse)
+            gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+            recs, found, counts = gm.scan_offsets(int(want.sum()) + 4)
+            assert found == int(want.sum()) and counts.tolist() == want.tolist()
+            assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in recs) == _expected_matches(payloads, pats)
+            assert gm.scan()[0].tolist() == want.tolist()
     gm.set_option(7, 1)
     gm.set_option(OPT_KERNEL, KERNEL_AUTO)
 
