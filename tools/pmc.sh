@@ -2,7 +2,7 @@
 # Tuning/profiling only: PMC passes over bench.py (each pass is its own rocprofv3 run).
 set -u
 OUT=gpurun_out/prof/pmc_$1; shift
-PROG=${PMC_PROG:-bench.py --steps 6 --warmup 2 --settle 20 --no-cpu-baseline}
+PROG=${PMC_PROG:-bench.py --steps 6 --warmup 2 --settle 20 --no-cpu-baseline --no-extra}
 KERN=${PMC_KERNEL:-kmp_scan}
 mkdir -p $OUT
 i=0
