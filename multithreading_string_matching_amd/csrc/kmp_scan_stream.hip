@@ -298,7 +298,12 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                         uint64_t nx;                                                    /* start bits of the next chunk */
                         if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
                         else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
-                        if (!EMIT && pad_clean) {
+                        const uint64_t last_lanes = (st >> 1) | (nx << 63);           /* the lanes behind which a packet starts */
+                        if (!EMIT && pad_clean && m <= 16u && (cl & last_lanes) == 0ull) {
+                            /* (see the next branch) no candidate sits in the last lane of its slot: every one of them has 32
+                             * bytes of slot or more from its first byte, all 16 start offsets fit a pattern of up to 16 bytes */
+                            maxi = fz != 0u ? 15 : -1;
+                        } else if (!EMIT && pad_clean) {
                             /* Slot padding is all 0x00 (checked when the arena was loaded), so "the window lies inside
                              * the payload" = "it lies inside the slot and holds no 0x00": the distance to the next
                              * packet start, read off the bitmap, replaces the payload's offset and length -- no
@@ -321,7 +326,6 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
                         }
                         if (zl != 0ull || dead_in) {
                             /* a 0x00 in the last lane of a packet ends nothing but that lane's own later offsets (see kmp_scan_flat_kernel) */
-                            const uint64_t last_lanes = (st >> 1) | (nx << 63);
                             if (dead_in || (zl & ~last_lanes) != 0ull) maxi = nul_limit(maxi, w, zl, st, dead_in, lane);
                             else if (ballot64(zm != 0u && fz != 0u) != 0ull) maxi = nul_limit(maxi, w, 0ull, st, false, lane);
                         }
