@@ -44,6 +44,10 @@ namespace {
 constexpr uint32_t QCAP = 96u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
 constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a time */
 
+/* (base + k) mod QCAP for base < QCAP (wave-uniform) and k < QCAP: no division */
+__device__ __forceinline__ uint32_t ring_slot(uint32_t base, uint32_t k) { const uint32_t x = base + k; return min(x, x - QCAP); }
+__device__ __forceinline__ uint32_t ring_wrap(uint32_t x) { return x >= QCAP ? x - QCAP : x; }           /* x < 2 * QCAP */
+
 template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
@@ -173,7 +177,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
          * (one in nine) goes back to the end of the queue with that hit left in its mask, so every round of this stage
          * runs with all its lanes busy instead of looping for the few records that need it. */
         auto process_batch = [&](uint32_t nproc) {
-            const uint32_t slot = (q_head + lane) % QCAP;
+            const uint32_t slot = ring_slot(q_head, lane);
             const uint4 r0 = q[2u * slot], r1 = q[2u * slot + 1u];
             const uint32_t t[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};        /* the lane's 16 text bytes and the 8 behind them */
             const bool act = lane < nproc;
@@ -189,14 +193,14 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
             const uint32_t T0 = __builtin_amdgcn_alignbyte(x1, x0, i);             /* shift = i & 3 bytes */
             const uint32_t T1 = __builtin_amdgcn_alignbyte(x2, x1, i);
             const uint2 bk = reinterpret_cast<const uint2 *>(s_bucket)[(uint32_t)__umul24(T0 & bmask, KMP_MULTI_MUL) >> 22];      /* KMP_MULTI_HASH */
-            q_head = (q_head + nproc) % QCAP;
+            q_head = ring_wrap(q_head + nproc);
             q_count -= nproc;
             const uint64_t again = ballot64(rest != 0u);
             if (again != 0ull) {
                 /* at most `nproc` (<= 64) records come back; QCAP - 64 stayed at most */
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
                 if (rest != 0u) {
-                    const uint32_t s2 = (q_head + q_count + rank) % QCAP;
+                    const uint32_t s2 = ring_slot(ring_wrap(q_head + q_count), rank);
                     q[2u * s2]      = r0;
                     q[2u * s2 + 1u] = make_uint4(r1.x, r1.y, rest | (rem << 16), r1.w);
                 }
@@ -299,7 +303,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                         int32_t nl = 15;                                             /* last start offset no 0x00 precedes */
                         if (dead_in || (zl & ~last_lanes) != 0ull) nl = nul_limit(15, w, zl, st, dead_in, lane);
                         else if (ballot64(zm != 0u && (ONES || hm != 0u)) != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);
-                        const int32_t lim = min(nl, rem - (int32_t)KMP_MULTI_MIN_LEN);
+                        /* (the payload's end is not applied to the hit mask: level 2 checks every hit's room, m <= rem - offset) */
                         if constexpr (ONES) {
                             /* the 1-byte patterns: their byte against all 16 start offsets (v_mqsad with a one-byte reference),
                              * counted where the offset lies inside the payload and before any 0x00 */
@@ -338,7 +342,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                                 if constexpr (!EMIT) one_cnt[k] += (found & 0xFFFFu) + (found >> 16);
                             }
                         }
-                        hm = (lim < 0) ? 0u : (hm & ((2u << lim) - 1u));
+                        if (ballot64(nl < 15) != 0ull) hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
                         if (ablate == 2u) hm = 0u;
                         const uint64_t hl_ = ballot64(hm != 0u);                    /* the lanes that have a hit */
                         if (hl_ != 0ull) {
@@ -348,7 +352,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                             const uint32_t w5 = wave_shl1(v.y, sgpr(bn.y));        /* text bytes 20..23 from the lane's first: a hit near its end carries 8 bytes too */
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hl_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hl_, 0u));
                             if (hm != 0u) {
-                                const uint32_t slot = (q_head + q_count + rank) % QCAP;
+                                const uint32_t slot = ring_slot(ring_wrap(q_head + q_count), rank);
                                 q[2u * slot]      = v;
                                 q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), cb + vo0);
                             }
