@@ -414,8 +414,9 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const size_t lds = kmp_multi_lds_bytes(table_words, n_unique) - (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t);      /* the dynamic part */
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
-    const char *abl = getenv("KMP_MULTI_ABLATE");                  /* tuning only (tools/fused_ablation.py): 1 = level 1 alone, 2 = + hit masking, 3 = + queueing */
-    const uint32_t ablate = abl ? (uint32_t)atoi(abl) : 0u;
+    /* tuning only (tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the kernel after a stage -- 1 = level 1
+     * alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  Read once per process. */
+    static const uint32_t ablate = []() { const char *e = getenv("KMP_MULTI_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
 #define KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, ONES_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_, ONES_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
         a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) do { if (n_ones) KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, true); else KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, false); } while (0)

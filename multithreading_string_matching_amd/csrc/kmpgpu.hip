@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -799,7 +800,13 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     };
 #define KMP_TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(KMPGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
     KMP_TRY2(hipMalloc(&d_file, span + 64));
-    const uint8_t *d_base = d_file - span_lo;           /* d_base[frame_off[f] ...] lies inside d_file for every frame given */
+    const uint8_t *d_base = d_file;                     /* the frame offsets are uploaded relative to the span's first byte */
+    std::vector<uint64_t> rel;
+    if (span_lo) {
+        rel.resize(n_frames);
+        for (uint64_t f = 0; f < n_frames; f++) rel[f] = frame_off[f] - span_lo;
+        frame_off = rel.data();
+    }
     KMP_TRY2(hipMalloc(&d_foff, n_frames * sizeof(uint64_t)));
     KMP_TRY2(hipMalloc(&d_cl, n_frames * sizeof(uint32_t)));
     KMP_TRY2(hipMalloc(&d_ws, kmp_extract_ws_bytes(n_frames)));
@@ -1121,6 +1128,8 @@ RcclApi g_rccl;
 
 int rccl_load()
 {
+    static std::mutex mu;           /* contexts are per thread (bin/openmp_data brings its shards up on threads); the library handle is not */
+    std::lock_guard<std::mutex> lock(mu);
     static int state = 0;           /* 0 untried, 1 loaded, -1 failed */
     if (state == 1) return KMPGPU_OK;
     if (state == -1) return fail(KMPGPU_EHIP, "librccl.so could not be loaded");
