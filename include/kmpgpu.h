@@ -13,9 +13,10 @@
  * s with s + m_i <= E_k and payload_k[s : s+m_i] == pattern_i (overlapping starts all count).
  *
  * Conventions: plain pointers and sizes only; every function returns 0 or a negative KMPGPU_E*
- * code and never exits; kmpgpu_last_error() gives the text.  One context drives one GPU (one
- * process per GPU; multi-GPU sums the per-context counts, see kmpgpu_counts_device).  A context
- * is not thread-safe.  Host buffers passed in are borrowed for the call; device buffers created
+ * code and never exits; kmpgpu_last_error() gives the text (per thread).  One context drives one GPU;
+ * several GPUs = several contexts, in one process or one process each, whose counters are summed by
+ * RCCL (kmpgpu_comm_*, the MPI_Reduce of mpi_dumping.c:202).  A context is not thread-safe; different
+ * contexts may be driven from different threads.  Host buffers passed in are borrowed for the call; device buffers created
  * by the context are owned by it.
  */
 #ifndef KMPGPU_H
