@@ -994,11 +994,14 @@ def test_accumulate_option(gm, oracle):
     assert gm.scan()[0].tolist() == oracle.count_payloads(batches[-1], pats).tolist()      # overwrite again
 
 
-def test_cli_offsets_file(tokens, fixture_counts, tmp_path):
+@pytest.mark.parametrize("shards,extra", [("3", {}), ("1", {"KMPGPU_RCCL": "1"}), ("2", {"KMPGPU_DEVICE_EXTRACT": "1"})])
+def test_cli_offsets_file(tokens, fixture_counts, tmp_path, shards, extra):
+    """KMPGPU_OFFSETS_FILE: every match as "payload,offset,pattern"; also after an RCCL count reduce (the shards' own
+    counts are kept for the offsets pass) and with the extraction on the device (payload indices run over the shards)."""
     out = tmp_path / "offsets.csv"
     exe = os.path.join(_lib.BINDIR, "openmp_data")
-    env = dict(os.environ, KMPGPU_OFFSETS_FILE=str(out))
-    r = subprocess.run([exe, os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), "3"], capture_output=True,
+    env = dict(os.environ, KMPGPU_OFFSETS_FILE=str(out), **extra)
+    r = subprocess.run([exe, os.path.join(DATA, "big_udp.pcap"), os.path.join(DATA, "strings.txt"), shards], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
