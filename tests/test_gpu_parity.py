@@ -1225,3 +1225,49 @@ def test_fused_pass_counts_one_byte_patterns_on_the_side(gm, oracle):
     assert found == int(want.sum()) and counts.tolist() == want.tolist()
     assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in recs) == _expected_matches(payloads, pats)
     gm.set_option(OPT_FUSED, 2)
+
+
+def test_fused_pass_table_shapes(gm, oracle):
+    """The fused pass's table variants: more than eight 2-byte patterns (buckets keyed by two bytes instead of three), several
+    patterns in one bucket, patterns that share their first 8 / 20 / 40 bytes (the rest is compared from the arena), a record
+    with three hits (it goes back to the queue twice), matches that end on the last payload byte, dirty slot padding."""
+    import itertools
+    rng = random.Random(77)
+    base = bytes(rng.choice(b"abc") for _ in range(64))
+    pats = [bytes(p) for p in itertools.product(b"abc", repeat=2)]                       # nine 2-byte patterns
+    pats += [b"abc", b"abca", b"abcab", base[:8], base[:9], base[:21], base[:41], base[:40] + b"c", base[:40] + b"a", base[:20] + b"zz", base]
+    pats += [b"bcabcabca", b"cab", b"cabc"]
+    payloads = []
+    for k in range(600):
+        L = rng.randrange(0, 500)
+        b = bytearray(rng.choice(b"abc") for _ in range(L))
+        if L > 70 and rng.random() < 0.5:
+            s0 = rng.randrange(0, L - 64)
+            b[s0:s0 + 64] = base
+        if L > 64 and rng.random() < 0.3:
+            b[L - 64:] = base                                                            # a long match ending on the last byte
+        if L and rng.random() < 0.2:
+            b[rng.randrange(L)] = 0
+        payloads.append(bytes(b))
+    check_payloads(gm, oracle, payloads, pats, variants=((MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_AUTO)))
+    # the same through a borrowed arena whose slot padding continues the text (the kernels take the lengths from the index)
+    import torch
+    arena = K.HostArena.from_payloads(payloads)
+    dirty = np.array(arena.bytes)
+    for o, l in zip(arena.off, arena.len):
+        o, l = int(o), int(l)
+        end = o + max(16, (l + 15) // 16 * 16)
+        dirty[o + l:end] = np.frombuffer((base * 2)[:end - o - l], dtype=np.uint8)
+    want, _ = oracle.count(arena.bytes, arena.off, arena.len, pats)
+    d_arena = torch.from_numpy(dirty).cuda()
+    d_off = torch.from_numpy(arena.off.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(arena.len.astype(np.int32)).cuda()
+    torch.cuda.synchronize()
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_patterns(pats)
+    gm.attach_arena(d_arena, d_off, d_len)
+    for fused in (1, 0):
+        gm.set_option(OPT_FUSED, fused)
+        assert gm.scan()[0].tolist() == want.tolist(), fused
+    gm.set_option(OPT_FUSED, 2)
