@@ -37,15 +37,21 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
  *   [2048, 2560)     entries: b0 | b1 << 8 | b2 << 16 | unique-pattern id << 24; b2 = 0x00 for a 2-byte pattern
  *                    (v_msad_u8 skips a 0x00 reference byte: it matches whatever follows).  The unique patterns are
  *                    numbered short ones (2 or 3 bytes) first: id < n_short means the entry decides alone.
- *   [2560, 6656)     filter over the first three text bytes, one BYTE (0x00 / 0xFF) per slot, 16384 slots: slot
- *                    KMP_MULTI_SLOT(b0 | b1 << 8 | (b2 & 31) << 16) is 0xFF for every pattern of 3+ bytes, and for all 32
- *                    values of b2 & 31 for a 2-byte pattern (so one lookup serves both).  A whole byte per slot because
- *                    the kernel then needs no bit extraction: start offset i ANDs the byte with 1 << (i & 7) and ORs it
- *                    into its hit mask in one v_and_or_b32.
- *   [6656, ...)      one 4-word record per LONG unique pattern (4+ bytes; record = id - n_short): bytes 0-3, bytes 4-7,
+ *   [2560, 4672)     filter over the first three text bytes, as a PAIR table: the bytes are taken by their low five bits
+ *                    (codes c = b & 31), and entry KMP_MULTI_PAIR(c1, c2) = c1 + 33 * c2 (8 bytes, 1056 entries) holds
+ *                      word 0: bit c0 set  <=>  some pattern starts c0 c1 c2      ("which byte may stand BEFORE c1 c2")
+ *                      word 1: bit c3 set  <=>  some pattern starts c1 c2 c3      ("which byte may FOLLOW c1 c2")
+ *                    so ONE ds_read_b64 at the two middle bytes of a 4-byte window decides the two start offsets at its
+ *                    first and second byte: 8 LDS lookups per 16 text bytes instead of 16 (the lookups at random addresses
+ *                    are what the LDS spends its cycles on: 32 lanes on 32 bank pairs, ~3.5 cycles per half wavefront).
+ *                    A 2-byte pattern c0 c1 sets bit c0 of word 0 in all 32 entries (c1, *) and all of word 1 of entry
+ *                    (c0, c1).  No hash: letters of one case never share a bit, text gives no false hit (round 2's first
+ *                    filter, 16384 hashed slots: 42 % of its hits on lower-case text were collisions).  The factor 33
+ *                    spreads the entries over the bank pairs by c1 + c2 (one letter alone covers 26 of 32).
+ *   [4672, ...)      one 4-word record per LONG unique pattern (4+ bytes; record = id - n_short): bytes 0-3, bytes 4-7,
  *                    the byte mask of bytes 4-7, m | pattern index << 8 (a pattern of nine bytes or more compares its
  *                    rest against kmp_pattern_dev[index].pat)
- * The first 6656 words live in static LDS (their offsets fold into the ds_read offset field). */
+ * The first 4672 words live in static LDS (their offsets fold into the ds_read offset field). */
 #define KMP_MULTI_BUCKETS     1024u
 #define KMP_MULTI_BUCKET_W0   0u
 #define KMP_MULTI_ENTRY_W0    2048u
@@ -53,8 +59,8 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_MAX_ONES    4u       /* distinct 1-byte patterns the first group counts on the side */
 #define KMP_MULTI_MAX_TWO     8u       /* 2-byte patterns a group may hold and still be bucketed by three bytes */
 #define KMP_MULTI_FILTER_W0   2560u
-#define KMP_MULTI_FILTER_SLOTS 16384u
-#define KMP_MULTI_REC_W0      (KMP_MULTI_FILTER_W0 + KMP_MULTI_FILTER_SLOTS / 4u)
+#define KMP_MULTI_PAIR_ENTRIES 1056u
+#define KMP_MULTI_REC_W0      (KMP_MULTI_FILTER_W0 + KMP_MULTI_PAIR_ENTRIES * 2u)
 #define KMP_MULTI_REC_WORDS   4u
 #define KMP_MULTI_MAX_UNIQUE  256u
 #define KMP_MULTI_MIN_LEN     2u
@@ -62,7 +68,9 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_MAX_LEN     99u
 #define KMP_MULTI_KEYMASK     0x1FFFFFu                  /* b0, b1 and the low five bits of b2 */
 #define KMP_MULTI_MUL         0x9E3779u
-#define KMP_MULTI_SLOT(w24)   ((uint32_t)(((uint32_t)(w24) & KMP_MULTI_KEYMASK) * KMP_MULTI_MUL) >> 18)      /* v_and + v_mul_u32_u24 + v_lshrrev */
+#define KMP_MULTI_PAIR(b1, b2) (((uint32_t)(b1) & 31u) + 33u * ((uint32_t)(b2) & 31u))
+#define KMP_MULTI_BLOCK_WAVES   12u    /* the fused pass runs 512-thread blocks: two of them share a CU's LDS (43 KB of tables each) */
+#define KMP_MULTI_BLOCK_THREADS (KMP_MULTI_BLOCK_WAVES * KMP_WAVE)
 #define KMP_MULTI_HASH(key)   ((uint32_t)((uint32_t)(key) * KMP_MULTI_MUL) >> 22)                                           /* key already masked: v_mul_u32_u24 + v_lshrrev */
 
 #endif

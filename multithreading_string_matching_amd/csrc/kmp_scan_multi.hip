@@ -41,19 +41,31 @@ namespace {
  *     (Round 1 walked every lane's hits chunk by chunk: 2 rounds of ~40 dependent instructions and three LDS round trips
  *     with 7 % of the lanes doing work, 55 % of the kernel's time.)
  * ============================================================================================== */
-constexpr uint32_t QCAP = 96u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
+constexpr uint32_t QCAP = 80u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
 constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a time */
 
 /* (base + k) mod QCAP for base < QCAP (wave-uniform) and k < QCAP: no division */
 __device__ __forceinline__ uint32_t ring_slot(uint32_t base, uint32_t k) { const uint32_t x = base + k; return min(x, x - QCAP); }
 __device__ __forceinline__ uint32_t ring_wrap(uint32_t x) { return x >= QCAP ? x - QCAP : x; }           /* x < 2 * QCAP */
 
+/* word >> (byte K of sel & 31): the SDWA operand select reads the byte straight out of the register */
+template <int K>
+__device__ __forceinline__ uint32_t shr_by_byte(uint32_t word, uint32_t sel)
+{
+    uint32_t r;
+    if constexpr (K == 0)      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
+    else if constexpr (K == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
+    else if constexpr (K == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
+    else                       asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
+    return r;
+}
+
 template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES>
-__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+__global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
 kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
-                      uint32_t n_ones, uint32_t ones, uint32_t ablate, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
+                      uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
                       const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
@@ -66,8 +78,11 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 3u) & ~3u));
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
-    const uint64_t gw = (uint64_t)blockIdx.x * KMP_BLOCK_WAVES + wave;
-    const uint64_t k0 = plan[gw].k, k1 = plan[gw + 1].k;
+    /* the plan is cut for 4-wavefront blocks (blocks_x of them, like the other kernels'); a block here takes two of those */
+    const uint32_t gw_ = blockIdx.x * KMP_MULTI_BLOCK_WAVES + wave;
+    const bool idle = gw_ >= nwaves;
+    const uint32_t gw = idle ? 0u : gw_;
+    const uint64_t k0 = plan[gw].k, k1 = idle ? k0 : plan[gw + 1].k;
     /* the stream starts on the 128-byte line below the first packet (see kmp_scan_packed_kernel) */
     const uint64_t off_first = plan[gw].off;
     const uint32_t pre = (uint32_t)(off_first & 127ull), pl = pre >> 4;
@@ -83,13 +98,17 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
 
-    for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0; i += KMP_BLOCK_THREADS) s_fix[i] = tables[i];
-    for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
-    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS) s_cnt[i] = 0u;
+    {
+        const uint4 *t4 = reinterpret_cast<const uint4 *>(tables);
+        uint4 *s4 = reinterpret_cast<uint4 *>(s_fix);
+        for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0 / 4u; i += KMP_MULTI_BLOCK_THREADS) s4[i] = t4[i];
+    }
+    for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_MULTI_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
+    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_MULTI_BLOCK_THREADS) s_cnt[i] = 0u;
     __syncthreads();
     const uint32_t *s_bucket = s_fix + KMP_MULTI_BUCKET_W0;
     const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
-    const uint8_t  *s_filter = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
+    const uint8_t  *s_pair   = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
     uint4 *q = s_q + wave * (2u * QCAP);         /* this wavefront's queue: a ring of 32-byte records {24 text bytes, hit mask | room << 16, position} */
     uint32_t q_head = 0u, q_count = 0u;          /* wave-uniform */
     uint32_t one_cnt[KMP_MULTI_MAX_ONES] = {0u, 0u, 0u, 0u};      /* this lane's matches of the 1-byte patterns that ride along */
@@ -279,20 +298,30 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                         remc = remn;
                     }
 
-                    /* level 1: which start offsets may begin some pattern (filter over the first three bytes)?  Start offset
-                     * i takes plane i & 7 of its filter byte. */
-                    uint32_t hm = 0u, hm_hi = 0u;
+                    /* level 1: which start offsets may begin some pattern (filter over the first three bytes)?  The bytes go
+                     * by their low five bits (x: the codes, x8: eight times the codes).  One 8-byte table entry, addressed by the
+                     * two MIDDLE bytes of a 4-byte window (v_dot4_u32_u8 with the weights {0, 1, 33, 0} on x8 is the entry's
+                     * byte offset), decides the start offsets at the window's first and second byte: word 0 has a bit per
+                     * byte that may stand before the middle pair, word 1 a bit per byte that may follow it (kmp_device.h).
+                     * Each word is shifted by its byte (SDWA picks the byte out of x, no extraction) and v_alignbit pushes
+                     * bit 0 of the result into the hit mask: 8 lookups and ~52 VALU per 16 text bytes. */
+                    uint32_t x[5], x8[5];
+#pragma unroll
+                    for (int q4 = 0; q4 < 5; ++q4) { x[q4] = w[q4] & 0x1F1F1F1Fu; x8[q4] = x[q4] << 3; }
+                    uint32_t hm = 0u;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const uint32_t d0 = a ? __builtin_amdgcn_alignbyte(w[q4 + 1], w[q4], a) : w[q4];
-                            const uint32_t fb = s_filter[(uint32_t)__umul24(d0 & KMP_MULTI_KEYMASK, KMP_MULTI_MUL) >> 18];      /* KMP_MULTI_SLOT (the cast: __umul24 is typed int, the shift must be logical) */
-                            if (q4 < 2) hm    = (fb & (1u << ((4 * q4 + a) & 7))) | hm;
-                            else        hm_hi = (fb & (1u << ((4 * q4 + a) & 7))) | hm_hi;
-                        }
+                        /* start offsets 4q, 4q + 1: the window is dword q */
+                        const uint2 e0 = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
+                        hm = __builtin_amdgcn_alignbit(shr_by_byte<0>(e0.x, x[q4]), hm, 1u);
+                        hm = __builtin_amdgcn_alignbit(shr_by_byte<3>(e0.y, x[q4]), hm, 1u);
+                        /* start offsets 4q + 2, 4q + 3: the window is bytes 2 .. 5 from dword q */
+                        const uint32_t y8 = __builtin_amdgcn_alignbyte(x8[q4 + 1], x8[q4], 2u);
+                        const uint2 e1 = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(y8, 0x00210100u, 0u, false));
+                        hm = __builtin_amdgcn_alignbit(shr_by_byte<2>(e1.x, x[q4]), hm, 1u);
+                        hm = __builtin_amdgcn_alignbit(shr_by_byte<1>(e1.y, x[q4 + 1]), hm, 1u);
                     }
-                    hm |= hm_hi << 8;
+                    hm >>= 16;                                                  /* sixteen pushes: the first one has reached bit 16 */
                     if (ablate == 1u) hm = 0u;
                     if (ONES || ballot64(hm != 0u) != 0ull) {
                         /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
@@ -394,8 +423,11 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
         if (lane == 0u) atomicAdd(&s_cnt[n_unique - n_ones + k], c);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_BLOCK_THREADS)
-        partials[(uint64_t)i * gridDim.x + blockIdx.x] = s_cnt[i];
+    /* partials[row][blocks_x]: there are fewer blocks here than columns; the columns nobody counts into are zeroed */
+    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_MULTI_BLOCK_THREADS) {
+        partials[(uint64_t)i * pstride + blockIdx.x] = s_cnt[i];
+        for (uint32_t c = blockIdx.x + gridDim.x; c < pstride; c += gridDim.x) partials[(uint64_t)i * pstride + c] = 0ull;
+    }
 }
 
 }  // namespace
@@ -403,7 +435,7 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
 /* LDS one block of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
 size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique)
 {
-    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_BLOCK_WAVES * QCAP * 8u) * sizeof(uint32_t);
+    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_MULTI_BLOCK_WAVES * QCAP * 8u) * sizeof(uint32_t);
 }
 
 /* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
@@ -417,8 +449,8 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     /* tuning only (tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the kernel after a stage -- 1 = level 1
      * alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  Read once per process. */
     static const uint32_t ablate = []() { const char *e = getenv("KMP_MULTI_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
-#define KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, ONES_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_, ONES_>), dim3(a.blocks_x), dim3(KMP_BLOCK_THREADS), lds, st, \
-        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.partials, em, uid_first, uid_ids, a.patterns)
+#define KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, ONES_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + KMP_MULTI_BLOCK_WAVES - 1u) / KMP_MULTI_BLOCK_WAVES), dim3(KMP_MULTI_BLOCK_THREADS), lds, st, \
+        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) do { if (n_ones) KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, true); else KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, false); } while (0)
     if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, false, true); }
     else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true, false); else KMP_MULTI_LAUNCH(false, true, false); }

@@ -158,7 +158,8 @@ uint32_t grid_blocks(const kmpgpu_ctx *c)
          * run as a second round), at most 7 */
         size_t lds = 1;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) lds = std::max(lds, kmp_multi_lds_bytes(g.words, g.n_unique));
-        fused_bpc = (int)std::max<size_t>(1, std::min<size_t>(7, (160u * 1024u) / (lds + 512u)));
+        /* (kmp_multi_lds_bytes is what one 8-wavefront block of that kernel takes: two of this function's blocks) */
+        fused_bpc = (int)std::max<size_t>(2, std::min<size_t>(8, (KMP_MULTI_BLOCK_WAVES / KMP_BLOCK_WAVES) * ((160u * 1024u) / (lds + 512u))));
     }
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
                   : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
@@ -616,11 +617,17 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         for (uint32_t u = 0; u < U; u++) {
             const std::string &p = h.uniq[u];
             const uint32_t w16 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8);
-            uint8_t *filter = reinterpret_cast<uint8_t *>(tab.data() + KMP_MULTI_FILTER_W0);
+            uint32_t *pair = tab.data() + KMP_MULTI_FILTER_W0;
+            if (p.size() >= 3) {
+                pair[2u * KMP_MULTI_PAIR(p[1], p[2])]      |= 1u << ((uint8_t)p[0] & 31u);       /* p0 may stand before p1 p2 */
+                pair[2u * KMP_MULTI_PAIR(p[0], p[1]) + 1u] |= 1u << ((uint8_t)p[2] & 31u);       /* p2 may follow p0 p1       */
+            } else {
+                for (uint32_t t = 0; t < 32u; t++) pair[2u * KMP_MULTI_PAIR(p[1], t)] |= 1u << ((uint8_t)p[0] & 31u);
+                pair[2u * KMP_MULTI_PAIR(p[0], p[1]) + 1u] = 0xFFFFFFFFu;                       /* whatever follows        */
+            }
             for (uint32_t t = 0; t < 32u; t++) {                      /* a 2-byte pattern matches whatever follows it */
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : t;
                 const uint32_t w24 = w16 | (third << 16);
-                filter[KMP_MULTI_SLOT(w24)] = 0xFFu;
                 std::vector<uint32_t> &l = lists[KMP_MULTI_HASH(w24 & bmask)];
                 if (l.empty() || l.back() != u) l.push_back(u);
                 if (p.size() >= 3) break;
