@@ -69,7 +69,7 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_KEYMASK     0x1FFFFFu                  /* b0, b1 and the low five bits of b2 */
 #define KMP_MULTI_MUL         0x9E3779u
 #define KMP_MULTI_PAIR(b1, b2) (((uint32_t)(b1) & 31u) + 33u * ((uint32_t)(b2) & 31u))
-#define KMP_MULTI_BLOCK_WAVES   12u    /* the fused pass runs 512-thread blocks: two of them share a CU's LDS (43 KB of tables each) */
+#define KMP_MULTI_BLOCK_WAVES   16u    /* the fused pass runs 1024-thread blocks: two of them share a CU (8 wavefronts per SIMD at 64 VGPRs, 2 x 60 KB of LDS) */
 #define KMP_MULTI_BLOCK_THREADS (KMP_MULTI_BLOCK_WAVES * KMP_WAVE)
 #define KMP_MULTI_HASH(key)   ((uint32_t)((uint32_t)(key) * KMP_MULTI_MUL) >> 22)                                           /* key already masked: v_mul_u32_u24 + v_lshrrev */
 

@@ -61,8 +61,8 @@ __device__ __forceinline__ uint32_t shr_by_byte(uint32_t word, uint32_t sel)
 }
 
 template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES>
-__global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
-kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
+__device__ __forceinline__ void
+kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
                       uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
@@ -313,13 +313,16 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
                     for (int q4 = 0; q4 < 4; ++q4) {
                         /* start offsets 4q, 4q + 1: the window is dword q */
                         const uint2 e0 = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
-                        hm = __builtin_amdgcn_alignbit(shr_by_byte<0>(e0.x, x[q4]), hm, 1u);
-                        hm = __builtin_amdgcn_alignbit(shr_by_byte<3>(e0.y, x[q4]), hm, 1u);
                         /* start offsets 4q + 2, 4q + 3: the window is bytes 2 .. 5 from dword q */
                         const uint32_t y8 = __builtin_amdgcn_alignbyte(x8[q4 + 1], x8[q4], 2u);
                         const uint2 e1 = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(y8, 0x00210100u, 0u, false));
-                        hm = __builtin_amdgcn_alignbit(shr_by_byte<2>(e1.x, x[q4]), hm, 1u);
-                        hm = __builtin_amdgcn_alignbit(shr_by_byte<1>(e1.y, x[q4 + 1]), hm, 1u);
+                        /* (both shifts of a pair before their pushes: nothing waits on the instruction just issued) */
+                        const uint32_t h0 = shr_by_byte<0>(e0.x, x[q4]), h1 = shr_by_byte<3>(e0.y, x[q4]);
+                        hm = __builtin_amdgcn_alignbit(h0, hm, 1u);
+                        hm = __builtin_amdgcn_alignbit(h1, hm, 1u);
+                        const uint32_t h2 = shr_by_byte<2>(e1.x, x[q4]), h3 = shr_by_byte<1>(e1.y, x[q4 + 1]);
+                        hm = __builtin_amdgcn_alignbit(h2, hm, 1u);
+                        hm = __builtin_amdgcn_alignbit(h3, hm, 1u);
                     }
                     hm >>= 16;                                                  /* sixteen pushes: the first one has reached bit 16 */
                     if (ablate == 1u) hm = 0u;
@@ -430,6 +433,37 @@ kmp_scan_multi_kernel(const uint8_t *__restrict__ arena, const uint32_t *__restr
     }
 }
 
+/* Two entry points: the counting pass is held to 64 VGPRs, so that two 16-wavefront blocks (8 wavefronts per SIMD) share
+ * a CU -- its rare paths spill a handful of registers for that; the pass that also writes offset records needs twice the
+ * registers and keeps them (one block per CU). */
+#define KMP_MULTI_PARAMS const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,          \
+                         const kmp_plan_entry *__restrict__ plan, const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,         \
+                         uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride,          \
+                         unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,                                 \
+                         const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns
+#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, n_short, bmask, n_ones, ones, ablate, nwaves, pstride, partials, em, uid_first, uid_ids, patterns
+
+template <int DEPTH, bool NT, bool CLEAN, bool ONES>
+__global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+kmp_scan_multi_kernel(KMP_MULTI_PARAMS)
+{
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES>(KMP_MULTI_ARGS);
+}
+
+template <int DEPTH, bool NT, bool CLEAN, bool ONES>
+__global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
+kmp_scan_multi_ones_kernel(KMP_MULTI_PARAMS)
+{
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, true>(KMP_MULTI_ARGS);
+}
+
+template <int DEPTH, bool NT, bool CLEAN, bool ONES>
+__global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
+kmp_scan_multi_emit_kernel(KMP_MULTI_PARAMS)
+{
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, true, ONES>(KMP_MULTI_ARGS);
+}
+
 }  // namespace
 
 /* LDS one block of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
@@ -449,12 +483,16 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     /* tuning only (tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the kernel after a stage -- 1 = level 1
      * alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  Read once per process. */
     static const uint32_t ablate = []() { const char *e = getenv("KMP_MULTI_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
-#define KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, ONES_) hipLaunchKernelGGL((kmp_scan_multi_kernel<4, NT_, CLEAN_, EMIT_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + KMP_MULTI_BLOCK_WAVES - 1u) / KMP_MULTI_BLOCK_WAVES), dim3(KMP_MULTI_BLOCK_THREADS), lds, st, \
-        a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, a.partials, em, uid_first, uid_ids, a.patterns)
-#define KMP_MULTI_LAUNCH(NT_, CLEAN_, EMIT_) do { if (n_ones) KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, true); else KMP_MULTI_LAUNCH1(NT_, CLEAN_, EMIT_, false); } while (0)
-    if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, false, true); }
-    else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(true, true, false); else KMP_MULTI_LAUNCH(false, true, false); }
-    else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(true, false, false); else KMP_MULTI_LAUNCH(false, false, false); }
+#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + KMP_MULTI_BLOCK_WAVES - 1u) / KMP_MULTI_BLOCK_WAVES), \
+        dim3(KMP_MULTI_BLOCK_THREADS), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, \
+        a.partials, em, uid_first, uid_ids, a.patterns)
+#define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
+        if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \
+        else if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_ones_kernel, NT_, CLEAN_, true);                                           \
+        else KMP_MULTI_LAUNCH1(kmp_scan_multi_kernel, NT_, CLEAN_, false); } while (0)
+    if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, true, false); }
+    else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(false, true, true); else KMP_MULTI_LAUNCH(false, false, true); }
+    else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(false, true, false); else KMP_MULTI_LAUNCH(false, false, false); }
 #undef KMP_MULTI_LAUNCH
 #undef KMP_MULTI_LAUNCH1
     return hipGetLastError();

@@ -158,8 +158,10 @@ uint32_t grid_blocks(const kmpgpu_ctx *c)
          * run as a second round), at most 7 */
         size_t lds = 1;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) lds = std::max(lds, kmp_multi_lds_bytes(g.words, g.n_unique));
-        /* (kmp_multi_lds_bytes is what one 8-wavefront block of that kernel takes: two of this function's blocks) */
-        fused_bpc = (int)std::max<size_t>(2, std::min<size_t>(8, (KMP_MULTI_BLOCK_WAVES / KMP_BLOCK_WAVES) * ((160u * 1024u) / (lds + 512u))));
+        /* (kmp_multi_lds_bytes is what one block of that kernel takes, KMP_MULTI_BLOCK_WAVES wavefronts; this function
+         * counts in 4-wavefront blocks, the unit the plan is cut in; 28 wavefronts per CU is what the kernel's ~70 VGPRs allow) */
+        const size_t fit = std::max<size_t>(1, std::min<size_t>((160u * 1024u) / (lds + 512u), 32u / KMP_MULTI_BLOCK_WAVES));
+        fused_bpc = (int)std::max<size_t>(1, fit * KMP_MULTI_BLOCK_WAVES / KMP_BLOCK_WAVES);
     }
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
                   : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
