@@ -308,19 +308,23 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     uint32_t x[5], x8[5];
 #pragma unroll
                     for (int q4 = 0; q4 < 5; ++q4) { x[q4] = w[q4] & 0x1F1F1F1Fu; x8[q4] = x[q4] << 3; }
+                    uint2 e[8];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        /* start offsets 4q, 4q + 1: the window is dword q; 4q + 2, 4q + 3: bytes 2 .. 5 from dword q */
+                        e[2 * q4] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
+                        const uint32_t y8 = __builtin_amdgcn_alignbyte(x8[q4 + 1], x8[q4], 2u);
+                        e[2 * q4 + 1] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(y8, 0x00210100u, 0u, false));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                          /* all eight lookups are on their way before the first result is used */
                     uint32_t hm = 0u;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        /* start offsets 4q, 4q + 1: the window is dword q */
-                        const uint2 e0 = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
-                        /* start offsets 4q + 2, 4q + 3: the window is bytes 2 .. 5 from dword q */
-                        const uint32_t y8 = __builtin_amdgcn_alignbyte(x8[q4 + 1], x8[q4], 2u);
-                        const uint2 e1 = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(y8, 0x00210100u, 0u, false));
                         /* (both shifts of a pair before their pushes: nothing waits on the instruction just issued) */
-                        const uint32_t h0 = shr_by_byte<0>(e0.x, x[q4]), h1 = shr_by_byte<3>(e0.y, x[q4]);
+                        const uint32_t h0 = shr_by_byte<0>(e[2 * q4].x, x[q4]), h1 = shr_by_byte<3>(e[2 * q4].y, x[q4]);
                         hm = __builtin_amdgcn_alignbit(h0, hm, 1u);
                         hm = __builtin_amdgcn_alignbit(h1, hm, 1u);
-                        const uint32_t h2 = shr_by_byte<2>(e1.x, x[q4]), h3 = shr_by_byte<1>(e1.y, x[q4 + 1]);
+                        const uint32_t h2 = shr_by_byte<2>(e[2 * q4 + 1].x, x[q4]), h3 = shr_by_byte<1>(e[2 * q4 + 1].y, x[q4 + 1]);
                         hm = __builtin_amdgcn_alignbit(h2, hm, 1u);
                         hm = __builtin_amdgcn_alignbit(h3, hm, 1u);
                     }

@@ -16,7 +16,7 @@ for name, pp in (("97", pats), ("97 + e, t", pats + [b"e", b"t"]), ("3+ bytes on
     m.set_patterns(pp); m.attach_arena(d_arena, d_off, d_len)
     for bpc in (0, 4, 8):
         m.set_option(OPT_BLOCKS_PER_CU, bpc)
-        for _ in range(20): m.scan_enqueue()
+        for _ in range(120 if bpc == 0 else 20): m.scan_enqueue()      # the first configuration also warms the clocks up
         m.sync()
         N = 40
         m.profile_begin(N)
