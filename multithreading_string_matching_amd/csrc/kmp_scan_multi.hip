@@ -83,9 +83,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     const bool idle = gw_ >= nwaves;
     const uint32_t gw = idle ? 0u : gw_;
     const uint64_t k0 = plan[gw].k, k1 = idle ? k0 : plan[gw + 1].k;
-    /* the stream starts on the 128-byte line below the first packet (see kmp_scan_packed_kernel) */
+    /* the stream starts on the 1 KiB boundary below the first packet (the packed kernel takes the 128-byte line): a chunk
+     * is then exactly one 64-bit word of the packet-start bitmap, no funnel shift per chunk */
     const uint64_t off_first = plan[gw].off;
-    const uint32_t pre = (uint32_t)(off_first & 127ull), pl = pre >> 4;
+    const uint32_t pre = (uint32_t)(off_first & (uint64_t)(KMP_CHUNK - 1u)), pl = pre >> 4;
     const uint64_t off0 = off_first - pre;
     const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;
 
@@ -116,7 +117,6 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     if (range) {
         const uint64_t b0 = off0 >> 4;
         const unsigned long long *bw = bitmap + (b0 >> 6);
-        const uint32_t sh = (uint32_t)(b0 & 63ull);
 
         unsigned long long hiw[DEPTH];
 #pragma unroll
@@ -234,7 +234,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
                 const unsigned long long hi = hiw[s];
-                st_[s] = sh ? ((low >> sh) | (hi << (64u - sh))) : low;
+                st_[s] = low;
                 low = hi;
                 asm volatile("" : "+s"(st_[s]));      /* computed HERE, not sunk below the loads that follow */
             }
@@ -249,20 +249,27 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     uint4 v = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
                     const u32x4 bn = buf[(s + 1) % DEPTH];
                     uint64_t st = st_[s];
+                    /* (real branches: both cases happen once per range, the selects they would otherwise become cost every chunk) */
                     if (s == 0 && cb == 0u && pl != 0u) {                               /* lanes before the first packet: not ours */
+                        asm volatile("" ::: "memory");
                         if (lane < pl) v = make_uint4(0u, 0u, 0u, 0u);
                         st &= ~0ull << pl;
                     }
                     const uint32_t left = range - cb;
-                    if (left < KMP_CHUNK) st &= (1ull << (left >> 4)) - 1ull;        /* bits past the range belong to the next wavefront */
+                    if (left < KMP_CHUNK) {                                             /* bits past the range belong to the next wavefront */
+                        asm volatile("" ::: "memory");
+                        st &= (1ull << (left >> 4)) - 1ull;
+                    }
 
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
                     const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
                     const uint64_t zl = ballot64(zm != 0u);
                     const bool dead_in = dead;
-                    if (zl == 0ull) { if (st != 0ull) dead = false; }
-                    else            dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
+                    if (zl != 0ull) {
+                        asm volatile("" ::: "memory");
+                        dead = (st == 0ull) ? true : ((zl >> (63u - (uint32_t)__builtin_clzll(st))) != 0ull);
+                    } else dead = dead && st == 0ull;
 
                     /* rem: payload bytes left from this lane's first byte; last_lanes: the lanes behind which a packet starts */
                     int32_t rem = 0;
@@ -270,7 +277,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     {
                         uint64_t nx;                                                /* start bits of the next chunk */
                         if (s + 1 < DEPTH) nx = st_[(s + 1) % DEPTH];
-                        else               nx = sh ? ((low >> sh) | (hiw[0] << (64u - sh))) : low;
+                        else               nx = low;
                         const uint64_t sg = st_[s];                                 /* not cut at the range's end: the next wavefront's first start ends our last slot */
                         last_lanes = (sg >> 1) | (nx << 63);
                         if constexpr (CLEAN) {
@@ -316,7 +323,8 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                         const uint32_t y8 = __builtin_amdgcn_alignbyte(x8[q4 + 1], x8[q4], 2u);
                         e[2 * q4 + 1] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(y8, 0x00210100u, 0u, false));
                     }
-                    __builtin_amdgcn_sched_barrier(0);                          /* all eight lookups are on their way before the first result is used */
+                    /* all eight lookups are on their way before the first result is used */
+                    __builtin_amdgcn_sched_barrier(0);
                     uint32_t hm = 0u;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
@@ -437,9 +445,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     }
 }
 
-/* Two entry points: the counting pass is held to 64 VGPRs, so that two 16-wavefront blocks (8 wavefronts per SIMD) share
- * a CU -- its rare paths spill a handful of registers for that; the pass that also writes offset records needs twice the
- * registers and keeps them (one block per CU). */
+/* Three entry points: the counting pass over clean padding (every arena this library builds) is held to 64 VGPRs, so that
+ * two 16-wavefront blocks (8 wavefronts per SIMD) share a CU; with 1-byte patterns riding along, or with the per-packet
+ * length loop of unclean padding, it needs a few registers more and keeps them ("wide": one block per CU), and the pass
+ * that also writes offset records needs twice as many. */
 #define KMP_MULTI_PARAMS const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,          \
                          const kmp_plan_entry *__restrict__ plan, const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,         \
                          uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride,          \
@@ -456,9 +465,9 @@ kmp_scan_multi_kernel(KMP_MULTI_PARAMS)
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
-kmp_scan_multi_ones_kernel(KMP_MULTI_PARAMS)
+kmp_scan_multi_wide_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, true>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES>(KMP_MULTI_ARGS);
 }
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
@@ -492,8 +501,9 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
         a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
         if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \
-        else if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_ones_kernel, NT_, CLEAN_, true);                                           \
-        else KMP_MULTI_LAUNCH1(kmp_scan_multi_kernel, NT_, CLEAN_, false); } while (0)
+        else if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_wide_kernel, NT_, CLEAN_, true);                                           \
+        else if (!(CLEAN_)) KMP_MULTI_LAUNCH1(kmp_scan_multi_wide_kernel, NT_, CLEAN_, false);                                       \
+        else KMP_MULTI_LAUNCH1(kmp_scan_multi_kernel, NT_, true, false); } while (0)
     if (a.emit_out) { if (a.pad_clean) KMP_MULTI_LAUNCH(true, true, true); else KMP_MULTI_LAUNCH(true, true, false); }
     else if (a.pad_clean) { if (a.nontemporal) KMP_MULTI_LAUNCH(false, true, true); else KMP_MULTI_LAUNCH(false, false, true); }
     else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(false, true, false); else KMP_MULTI_LAUNCH(false, false, false); }
