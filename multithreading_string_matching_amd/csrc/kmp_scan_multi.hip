@@ -48,16 +48,18 @@ constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a ti
 __device__ __forceinline__ uint32_t ring_slot(uint32_t base, uint32_t k) { const uint32_t x = base + k; return min(x, x - QCAP); }
 __device__ __forceinline__ uint32_t ring_wrap(uint32_t x) { return x >= QCAP ? x - QCAP : x; }           /* x < 2 * QCAP */
 
-/* word >> (byte K of sel & 31): the SDWA operand select reads the byte straight out of the register */
-template <int K>
-__device__ __forceinline__ uint32_t shr_by_byte(uint32_t word, uint32_t sel)
+/* Byte D of acc = low byte of word >> (byte K of sel & 31); D == 0 also clears the other three bytes.  SDWA picks the shift
+ * amount out of the text register and drops the result into its byte of the accumulator: one instruction per start offset. */
+template <int K, int D>
+__device__ __forceinline__ void shr_by_byte_into(uint32_t &acc, uint32_t word, uint32_t sel)
 {
-    uint32_t r;
-    if constexpr (K == 0)      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
-    else if constexpr (K == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
-    else if constexpr (K == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
-    else                       asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(sel), "v"(word));
-    return r;
+#define KMP_SHR_SDWA(K_, D_, UNUSED_) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_" #D_ " dst_unused:" UNUSED_ " src0_sel:BYTE_" #K_ " src1_sel:DWORD" : "+v"(acc) : "v"(sel), "v"(word))
+    static_assert((K == 0 && D == 0) || (K == 3 && D == 1) || (K == 2 && D == 2) || (K == 1 && D == 3), "the four start offsets of a dword");
+    if constexpr (D == 0)      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(acc) : "v"(sel), "v"(word));
+    else if constexpr (D == 1) KMP_SHR_SDWA(3, 1, "UNUSED_PRESERVE");
+    else if constexpr (D == 2) KMP_SHR_SDWA(2, 2, "UNUSED_PRESERVE");
+    else                       KMP_SHR_SDWA(1, 3, "UNUSED_PRESERVE");
+#undef KMP_SHR_SDWA
 }
 
 template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES>
@@ -312,9 +314,9 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                      * byte that may stand before the middle pair, word 1 a bit per byte that may follow it (kmp_device.h).
                      * Each word is shifted by its byte (SDWA picks the byte out of x, no extraction) and v_alignbit pushes
                      * bit 0 of the result into the hit mask: 8 lookups and ~52 VALU per 16 text bytes. */
-                    uint32_t x[5], x8[5];
+                    uint32_t x8[5];
 #pragma unroll
-                    for (int q4 = 0; q4 < 5; ++q4) { x[q4] = w[q4] & 0x1F1F1F1Fu; x8[q4] = x[q4] << 3; }
+                    for (int q4 = 0; q4 < 5; ++q4) x8[q4] = (w[q4] & 0x1F1F1F1Fu) << 3;
                     uint2 e[8];
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
@@ -325,19 +327,20 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     }
                     /* all eight lookups are on their way before the first result is used */
                     __builtin_amdgcn_sched_barrier(0);
-                    uint32_t hm = 0u;
+                    /* bit 0 of (word >> byte) is the verdict: the four of a dword land in the four bytes of one register, and a
+                     * v_dot4 with the weights {1, 2, 4, 8} ({16, 32, 64, 128} for the odd dwords) packs them into the hit mask */
+                    uint32_t hmq[2] = {0u, 0u};
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        /* (both shifts of a pair before their pushes: nothing waits on the instruction just issued) */
-                        const uint32_t h0 = shr_by_byte<0>(e[2 * q4].x, x[q4]), h1 = shr_by_byte<3>(e[2 * q4].y, x[q4]);
-                        hm = __builtin_amdgcn_alignbit(h0, hm, 1u);
-                        hm = __builtin_amdgcn_alignbit(h1, hm, 1u);
-                        const uint32_t h2 = shr_by_byte<2>(e[2 * q4 + 1].x, x[q4]), h3 = shr_by_byte<1>(e[2 * q4 + 1].y, x[q4 + 1]);
-                        hm = __builtin_amdgcn_alignbit(h2, hm, 1u);
-                        hm = __builtin_amdgcn_alignbit(h3, hm, 1u);
+                        uint32_t hb;
+                        shr_by_byte_into<0, 0>(hb, e[2 * q4].x, w[q4]);
+                        shr_by_byte_into<3, 1>(hb, e[2 * q4].y, w[q4]);
+                        shr_by_byte_into<2, 2>(hb, e[2 * q4 + 1].x, w[q4]);
+                        shr_by_byte_into<1, 3>(hb, e[2 * q4 + 1].y, w[q4 + 1]);
+                        hmq[q4 >> 1] = __builtin_amdgcn_udot4(hb & 0x01010101u, (q4 & 1) ? 0x80402010u : 0x08040201u, hmq[q4 >> 1], false);
                     }
-                    hm >>= 16;                                                  /* sixteen pushes: the first one has reached bit 16 */
-                    if (ablate == 1u) hm = 0u;
+                    uint32_t hm = hmq[0] | (hmq[1] << 8);
+                    if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == 1u) hm = 0u; }      /* tuning switch: a scalar branch, not a select per chunk */
                     if (ONES || ballot64(hm != 0u) != 0ull) {
                         /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
                          * and no 0x00 before them (strlen rule, serial.c:191).  Nearly every 0x00 of real traffic and all of the
@@ -387,7 +390,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                             }
                         }
                         if (ballot64(nl < 15) != 0ull) hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
-                        if (ablate == 2u) hm = 0u;
+                        if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == 2u) hm = 0u; }
                         const uint64_t hl_ = ballot64(hm != 0u);                    /* the lanes that have a hit */
                         if (hl_ != 0ull) {
                             /* append one record per such lane to the queue */
@@ -401,7 +404,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                                 q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), cb + vo0);
                             }
                             q_count += nnew;
-                            if (ablate == 3u) { q_head = 0u; q_count = 0u; }
+                            if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == 3u) { q_head = 0u; q_count = 0u; } }
                             if constexpr (EMIT) {
                                 e_st = st;
                                 while (q_count != 0u) process_batch(min(q_count, 64u));
