@@ -45,6 +45,19 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, int iters, unsigned long
         if (OP == 17) { REP64(asm volatile("v_pk_add_u16 %0, %0, %1\n v_pk_sub_u16 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
         if (OP == 18) { REP64(asm volatile("v_cmp_eq_u16 s[20:21], %0, %1\n v_cmp_eq_u16 s[22:23], %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "s20", "s21", "s22", "s23");) }
         if (OP == 19) { REP64(asm volatile("v_lshrrev_b64 %0, 8, %0\n v_lshrrev_b64 %1, 8, %1" : "+v"(q), "+v"(r));) }
+        if (OP == 30) { REP64(asm volatile("v_dot4_u32_u8 %0, %1, %2, %0\n v_dot4_u32_u8 %3, %4, %5, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));) }
+        if (OP == 31) { REP64(asm volatile("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD\n v_lshrrev_b32_sdwa %3, %4, %5 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));) }
+        if (OP == 32) { REP64(asm volatile("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_lshrrev_b32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));) }
+        if (OP == 33) { REP64(asm volatile("v_alignbit_b32 %0, %1, %0, 1\n v_alignbit_b32 %2, %3, %2, 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (OP == 34) { REP64(asm volatile("v_lshlrev_b32 %0, 3, %1\n v_and_b32 %2, 0xf8f8f8f8, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (OP == 35) { REP64(asm volatile("v_lshl_or_b32 %0, %1, 8, %0\n v_lshl_or_b32 %2, %3, 8, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (OP == 36) { REP64(asm volatile("v_mul_u32_u24 %0, %0, %1\n v_mul_u32_u24 %2, %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (OP == 37) { REP64(asm volatile("v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %3, %4, %5, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));) }
+        if (OP == 38) { REP64(asm volatile("v_bfe_u32 %0, %1, 5, 10\n v_bfe_u32 %2, %3, 15, 10" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (OP == 39) { REP64(asm volatile("v_lshrrev_b32 %0, %1, %0\n v_lshrrev_b32 %2, %3, %2" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
+        if (OP == 40) { REP64(asm volatile("v_xor_b32 %0, %0, %1\n s_nop 0" : "+v"(a), "+v"(b));) }
+        if (OP == 41) { REP64(asm volatile("v_xor_b32 %0, %0, %1\n s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));) }
+        if (OP == 42) { REP64(asm volatile("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_add_u32_sdwa %2, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + e + f + g + h + (uint32_t)q + (uint32_t)r + (uint32_t)q2;
@@ -81,5 +94,6 @@ int main(int argc, char **argv)
     RUN(3, "v_cmp_eq_u32 -> sgpr") RUN(18, "v_cmp_eq_u16 -> sgpr") RUN(15, "v_cmp vcc + v_addc") RUN(4, "v_qsad_pk_u16_u8")
     RUN(5, "v_pk_min_u16") RUN(17, "v_pk_add/sub_u16") RUN(6, "v_bitop3_b32") RUN(12, "v_perm_b32") RUN(13, "v_sad_u8")
     RUN(14, "v_msad_u8") RUN(16, "v_mov_b32_dpp wave_shl") RUN(19, "v_lshrrev_b64") RUN(7, "s_or_b64") RUN(8, "v_xor + s_or interleaved") RUN(20, "v_cmp->sgpr + s_or") RUN(21, "s_add_u32") RUN(22, "s_nop 4") RUN(23, "v_readfirstlane") RUN(24, "v_xor + 3 s_add") RUN(25, "s_cmp+branch (1 taken,1 not)") RUN(26, "v_cndmask vcc") RUN(27, "v_and_or/v_or3") RUN(28, "v_min_u32") RUN(29, "v_cmp_eq_u32 vcc (VOPC)")
+    RUN(30, "v_dot4_u32_u8") RUN(31, "v_lshrrev_sdwa byte->byte") RUN(32, "v_lshrrev_sdwa byte->dword") RUN(33, "v_alignbit_b32") RUN(34, "v_lshlrev/v_and (e32)") RUN(35, "v_lshl_or_b32") RUN(36, "v_mul_u32_u24") RUN(37, "v_mad_u32_u24") RUN(38, "v_bfe_u32") RUN(39, "v_lshrrev_b32 (vgpr shift)") RUN(40, "v_xor + s_nop 0") RUN(41, "v_xor + s_waitcnt") RUN(42, "v_add_u32_sdwa")
     return 0;
 }
