@@ -21,11 +21,12 @@ namespace {
  * balanced plan).  Per chunk:
  *   - rem = payload bytes left from the lane's first byte (CLEAN: two lane masks off the start bitmap; otherwise a
  *     uniform loop over the packet starts of the chunk with lengths by scalar loads);
- *   - level 1: the 3-byte window at each of the 16 start offsets is hashed (v_and + v_mul_u32_u24 + v_lshrrev) into a
- *     filter of 16384 one-byte slots in LDS, "some pattern may start with these bytes"; a whole byte per slot so that
- *     start offset i needs no bit extraction: it ANDs the byte with 1 << (i & 7) and ORs it into its hit mask in one
- *     instruction.  This level is bound by the LDS bank conflicts of its 16 random byte reads per lane, not by VALU
- *     (profiles/r02_fused_ablation.txt);
+ *   - level 1: "may some pattern start here?" for the 16 start offsets of the lane, TWO offsets per LDS lookup: the text
+ *     goes by 5-bit codes (b & 31), an 8-byte entry addressed by the two middle bytes of a 4-byte window says which bytes
+ *     may stand before that pair and which may follow it as the start of a pattern (kmp_device.h, pair table), so one
+ *     ds_read_b64 decides the offsets at the window's first and second byte.  v_dot4_u32_u8 computes the entry's
+ *     address, v_lshrrev_b32_sdwa shifts each word by its text byte, v_dot4 packs the verdicts into the hit mask.
+ *     This level is VALU-bound (profiles/r02_fused_ablation.txt: the LDS was the limit until the lookups were halved);
  *   - hits are not looked at here.  Every lane that has one appends ONE 32-byte record -- its 24 text bytes, its hit
  *     mask, the room up to the payload's end, its position -- to the wavefront's queue in LDS (slot = mbcnt over the
  *     ballot of those lanes: one ballot and two writes per chunk, no loop, no dependent LDS read), and whenever the

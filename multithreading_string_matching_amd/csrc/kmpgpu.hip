@@ -149,17 +149,17 @@ bool use_packed(const kmpgpu_ctx *c)
 uint32_t grid_blocks(const kmpgpu_ctx *c)
 {
     /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat kernel (HBM-bound from 3 on), 6 for
-     * the packed kernel (profiles/r01_packed_tuning.txt), 7 for the fused pass (latency-bound level 2; 7 blocks
-     * of LDS fit a CU; profiles/r01_fused_blocks_per_cu.txt), 8 for the general one */
+     * the packed kernel (profiles/r01_packed_tuning.txt), 8 for the general one; the fused pass takes what fits a CU
+     * (two of its 16-wavefront blocks = 8 of this function's 4-wavefront units, see below) */
     const bool streaming = use_flat(c) || use_packed(c);
     int fused_bpc = 7;
     if (use_fused(c)) {
         /* as many blocks as the CU's 160 KB of LDS hold (the grid is persistent: a block that cannot be resident would
-         * run as a second round), at most 7 */
+         * run as a second round) */
         size_t lds = 1;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) lds = std::max(lds, kmp_multi_lds_bytes(g.words, g.n_unique));
         /* (kmp_multi_lds_bytes is what one block of that kernel takes, KMP_MULTI_BLOCK_WAVES wavefronts; this function
-         * counts in 4-wavefront blocks, the unit the plan is cut in; 28 wavefronts per CU is what the kernel's ~70 VGPRs allow) */
+         * counts in 4-wavefront blocks, the unit the plan is cut in; 32 wavefronts per CU is what the counting kernel's 64 VGPRs allow) */
         const size_t fit = std::max<size_t>(1, std::min<size_t>((160u * 1024u) / (lds + 512u), 32u / KMP_MULTI_BLOCK_WAVES));
         fused_bpc = (int)std::max<size_t>(1, fit * KMP_MULTI_BLOCK_WAVES / KMP_BLOCK_WAVES);
     }
