@@ -1224,6 +1224,37 @@ def test_fused_pass_counts_one_byte_patterns_on_the_side(gm, oracle):
     recs, found, counts = gm.scan_offsets(int(want.sum()) + 8)
     assert found == int(want.sum()) and counts.tolist() == want.tolist()
     assert sorted((int(r["packet"]), int(r["offset"]), int(r["pattern"])) for r in recs) == _expected_matches(payloads, pats)
+
+
+def test_fused_filter_bytes_that_share_a_code(gm, oracle):
+    """The fused pass's filter sees text bytes by their low five bits only: bytes that share a code ('a' 'A' '!' 0x01 0x81 0xE1; code 0:
+    ' ' '@' '`' 0x80; code 31: '?' '_' 0x7F 0xFF) pass the filter for each other's patterns and must be told apart by level 2 -- text and
+    patterns drawn from exactly those bytes, every pattern length from 2 on, matches next to 0x00 bytes and across lane / chunk borders."""
+    rng = random.Random(4242)
+    groups = [bytes([0x61, 0x41, 0x21, 0x01, 0x81, 0xE1]), bytes([0x20, 0x40, 0x60, 0x80]), bytes([0x3F, 0x5F, 0x7F, 0xFF, 0x1F]), bytes([0x62, 0x42, 0xC2])]
+    alphabet = b"".join(groups)
+    pats = []
+    for m in (2, 2, 2, 3, 3, 3, 4, 5, 7, 8, 9, 12, 17, 33):
+        for _ in range(3):
+            pats.append(bytes(rng.choice(alphabet) for _ in range(m)))
+    pats += [b"aa", b"AA", b"a!", b"__", b"??", b"@@", b"  ", b" @`", bytes([0xFF, 0xFF]), bytes([0x81, 0x01, 0xE1])]
+    payloads = []
+    for k in range(900):
+        L = rng.choice((0, 1, 2, 3, 15, 16, 17, 31, 33, 64, 200, 1023, 1024, 1025, 1500, 3000)) if k % 3 else rng.randrange(0, 2200)
+        b = bytearray(rng.choice(alphabet) for _ in range(L))
+        for _ in range(rng.randrange(0, 4)):                                              # plant a few patterns, some on lane borders
+            q = rng.choice(pats)
+            if L > len(q) + 16:
+                at = rng.choice((rng.randrange(0, L - len(q)), (rng.randrange(16, L - len(q)) // 16) * 16 - rng.randrange(0, min(len(q), 15) + 1)))
+                b[at:at + len(q)] = q
+        if L and rng.random() < 0.25:
+            b[rng.randrange(L)] = 0
+        payloads.append(bytes(b))
+    check_payloads(gm, oracle, payloads, pats, variants=((MODE_FILTER, KERNEL_FUSED), (MODE_FILTER, KERNEL_AUTO)))
+    # and as one long stream of 64-byte packets (a packet start in every fourth lane)
+    check_payloads(gm, oracle, [bytes(rng.choice(alphabet) for _ in range(64)) for _ in range(5000)], pats[:40], variants=((MODE_FILTER, KERNEL_FUSED),))
+
+
     gm.set_option(OPT_FUSED, 2)
 
 
