@@ -76,7 +76,7 @@ def extra_configs(m, dev, passes, headline, sample97):
     pats97 = K.load_patterns(os.path.join(data, "strings.txt"))
     out = []
 
-    def timed(name, config, payload_bytes, check, note=None, settle=40):
+    def timed(name, config, payload_bytes, check, note=None, settle=200):      # settle: as for the headline, the clocks have dropped during the count check
         for _ in range(settle):
             m.scan_enqueue()
         m.sync()
