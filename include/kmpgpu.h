@@ -67,9 +67,9 @@ typedef struct kmpgpu_match {
 #define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8; 0 = auto */
 #define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: the patterns of 2..99
                                         bytes are counted in ONE read of a packed arena per 256
-                                        distinct patterns (1-byte patterns keep one read each);
-                                        0 = off; 2 = auto (default): fused from 3 such unique
-                                        patterns on                                            */
+                                        distinct patterns (up to four 1-byte patterns ride along,
+                                        further ones keep one read each); 0 = off; 2 = auto
+                                        (default): fused from 2 such unique patterns on         */
 #define KMPGPU_OPT_KERNEL        5   /* 0 auto: slots back to back -> packed streaming kernel, or
                                         the flat streaming kernel when every payload has the same
                                         length of 512 bytes or more (also taken for equal slots

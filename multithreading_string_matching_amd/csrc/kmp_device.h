@@ -71,6 +71,7 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_PAIR(b1, b2) (((uint32_t)(b1) & 31u) + 33u * ((uint32_t)(b2) & 31u))
 #define KMP_MULTI_BLOCK_WAVES   16u    /* the fused pass runs 1024-thread blocks: two of them share a CU (8 wavefronts per SIMD at 64 VGPRs, 2 x 60 KB of LDS) */
 #define KMP_MULTI_BLOCK_THREADS (KMP_MULTI_BLOCK_WAVES * KMP_WAVE)
+#define KMP_MULTI_WIDE_WAVES    12u    /* its variants that need up to ~80 VGPRs (1-byte patterns riding along, unclean padding): two blocks = 6 wavefronts per SIMD */
 #define KMP_MULTI_HASH(key)   ((uint32_t)((uint32_t)(key) * KMP_MULTI_MUL) >> 22)                                           /* key already masked: v_mul_u32_u24 + v_lshrrev */
 
 #endif

@@ -46,7 +46,10 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
                              int accumulate = 0);
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st);
-size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique);
+size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves);
+int kmp_multi_kind(bool emit, bool pad_clean, uint32_t n_ones);
+uint32_t kmp_multi_block_waves(int kind);
+uint32_t kmp_multi_resident_waves(int kind, uint32_t table_words, uint32_t n_unique);
 size_t kmp_extract_ws_bytes(uint64_t n_frames);
 hipError_t kmp_launch_extract_phase1(const uint8_t *file, const uint64_t *frame_off, const uint32_t *caplen, uint64_t n, int tcp,
                                      uint8_t *ws, unsigned long long *totals, hipStream_t st);

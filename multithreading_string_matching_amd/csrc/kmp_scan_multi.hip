@@ -63,7 +63,7 @@ __device__ __forceinline__ void shr_by_byte_into(uint32_t &acc, uint32_t word, u
 #undef KMP_SHR_SDWA
 }
 
-template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES>
+template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES, uint32_t WAVES>
 __device__ __forceinline__ void
 kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
@@ -82,7 +82,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     /* the plan is cut for 4-wavefront blocks (blocks_x of them, like the other kernels'); a block here takes two of those */
-    const uint32_t gw_ = blockIdx.x * KMP_MULTI_BLOCK_WAVES + wave;
+    const uint32_t gw_ = blockIdx.x * WAVES + wave;
     const bool idle = gw_ >= nwaves;
     const uint32_t gw = idle ? 0u : gw_;
     const uint64_t k0 = plan[gw].k, k1 = idle ? k0 : plan[gw + 1].k;
@@ -105,10 +105,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     {
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tables);
         uint4 *s4 = reinterpret_cast<uint4 *>(s_fix);
-        for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0 / 4u; i += KMP_MULTI_BLOCK_THREADS) s4[i] = t4[i];
+        for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0 / 4u; i += WAVES * KMP_WAVE) s4[i] = t4[i];
     }
-    for (uint32_t i = threadIdx.x; i < rec_words; i += KMP_MULTI_BLOCK_THREADS) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
-    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_MULTI_BLOCK_THREADS) s_cnt[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < rec_words; i += WAVES * KMP_WAVE) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
+    for (uint32_t i = threadIdx.x; i < n_unique; i += WAVES * KMP_WAVE) s_cnt[i] = 0u;
     __syncthreads();
     const uint32_t *s_bucket = s_fix + KMP_MULTI_BUCKET_W0;
     const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
@@ -266,7 +266,8 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
 
                     const uint32_t w[5] = {v.x, v.y, v.z, v.w, wave_shl1(v.x, sgpr(bn.x))};
 
-                    const uint32_t zm = zero_byte_mask(w[0]) | zero_byte_mask(w[1]) | zero_byte_mask(w[2]) | zero_byte_mask(w[3]);
+                    const uint32_t z[4] = {zero_byte_mask(w[0]), zero_byte_mask(w[1]), zero_byte_mask(w[2]), zero_byte_mask(w[3])};
+                    const uint32_t zm = z[0] | z[1] | z[2] | z[3];
                     const uint64_t zl = ballot64(zm != 0u);
                     const bool dead_in = dead;
                     if (zl != 0ull) {
@@ -349,10 +350,42 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                          * their own lane, and there only for a lane that has a hit -- the general, segmented form
                          * (nul_limit) is kept for a 0x00 in mid-packet. */
                         int32_t nl = 15;                                             /* last start offset no 0x00 precedes */
-                        if (dead_in || (zl & ~last_lanes) != 0ull) nl = nul_limit(15, w, zl, st, dead_in, lane);
-                        else if (ballot64(zm != 0u && (ONES || hm != 0u)) != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);
+                        /* (the 1-byte patterns over clean padding take care of a lane's own 0x00 themselves, below) */
+                        constexpr bool ONES_BY_MASK = ONES && CLEAN && !EMIT;
+                        const bool seg = dead_in || (zl & ~last_lanes) != 0ull;
+                        if (seg) nl = nul_limit(15, w, zl, st, dead_in, lane);
+                        else if (ballot64(zm != 0u && ((ONES && !ONES_BY_MASK) || hm != 0u)) != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);
                         /* (the payload's end is not applied to the hit mask: level 2 checks every hit's room, m <= rem - offset) */
-                        if constexpr (ONES) {
+                        if (ONES_BY_MASK && !seg) {
+                            /* The 1-byte patterns, common case: no 0x00 but in the last lane of a packet, padding all 0x00.  A text byte
+                             * counts iff it equals the pattern's byte and no 0x00 precedes it in its lane (the padding cannot match, the
+                             * payload's end needs no test): vm[q] has 0x80 for the bytes of dword q below the lane's first 0x00 --
+                             * ~z & (z - 1) & 0x80808080 per dword, nothing behind a dword that holds one; the haszero mask z may
+                             * flag a 0x01 ABOVE a real 0x00, which is behind the first one anyway -- and the exact zero-byte test of
+                             * w ^ byte, ~(((x & 0x7F..) + 0x7F..) | x), is ANDed with it in the same v_bitop3.  Five instructions
+                             * and one v_bcnt per dword and pattern (the v_mqsad form below: 7.7 ns per v_mqsad alone). */
+                            uint32_t vm[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+                            if (zl != 0ull) {
+                                asm volatile("" ::: "memory");
+                                vm[0] = ~z[0] & (z[0] - 1u) & 0x80808080u;
+                                vm[1] = z[0] ? 0u : (~z[1] & (z[1] - 1u) & 0x80808080u);
+                                vm[2] = (z[0] | z[1]) ? 0u : (~z[2] & (z[2] - 1u) & 0x80808080u);
+                                vm[3] = (z[0] | z[1] | z[2]) ? 0u : (~z[3] & (z[3] - 1u) & 0x80808080u);
+                            }
+#pragma unroll
+                            for (uint32_t k = 0; k < KMP_MULTI_MAX_ONES; ++k) {
+                                if (k >= n_ones) break;
+                                const uint32_t ref4 = ((ones >> (8u * k)) & 0xFFu) * 0x01010101u;
+                                uint32_t c = one_cnt[k];
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    const uint32_t x = w[q4] ^ ref4;
+                                    const uint32_t t7 = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+                                    c += (uint32_t)__builtin_popcount(~(t7 | x) & vm[q4]);
+                                }
+                                one_cnt[k] = c;
+                            }
+                        } else if constexpr (ONES) {
                             /* the 1-byte patterns: their byte against all 16 start offsets (v_mqsad with a one-byte reference),
                              * counted where the offset lies inside the payload and before any 0x00 */
                             const int32_t lim1 = min(nl, rem - 1);
@@ -443,16 +476,17 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     }
     __syncthreads();
     /* partials[row][blocks_x]: there are fewer blocks here than columns; the columns nobody counts into are zeroed */
-    for (uint32_t i = threadIdx.x; i < n_unique; i += KMP_MULTI_BLOCK_THREADS) {
+    for (uint32_t i = threadIdx.x; i < n_unique; i += WAVES * KMP_WAVE) {
         partials[(uint64_t)i * pstride + blockIdx.x] = s_cnt[i];
         for (uint32_t c = blockIdx.x + gridDim.x; c < pstride; c += gridDim.x) partials[(uint64_t)i * pstride + c] = 0ull;
     }
 }
 
-/* Three entry points: the counting pass over clean padding (every arena this library builds) is held to 64 VGPRs, so that
- * two 16-wavefront blocks (8 wavefronts per SIMD) share a CU; with 1-byte patterns riding along, or with the per-packet
- * length loop of unclean padding, it needs a few registers more and keeps them ("wide": one block per CU), and the pass
- * that also writes offset records needs twice as many. */
+/* Three entry points.  The counting pass over clean padding (every arena this library builds) is held to 64 VGPRs, so that
+ * two 16-wavefront blocks (8 wavefronts per SIMD) share a CU.  With 1-byte patterns riding along, or with the per-packet
+ * length loop of unclean padding, it needs up to ~80 registers: "wide", 12-wavefront blocks, two of them = 6 wavefronts per
+ * SIMD.  The pass that also writes offset records needs ~125: one 16-wavefront block per CU.  (The plan is cut for the
+ * wavefronts that are resident at once, kmp_multi_resident_waves(); a block counts in whichever size its kernel has.) */
 #define KMP_MULTI_PARAMS const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,          \
                          const kmp_plan_entry *__restrict__ plan, const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,         \
                          uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride,          \
@@ -464,29 +498,41 @@ template <int DEPTH, bool NT, bool CLEAN, bool ONES>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 kmp_scan_multi_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES, KMP_MULTI_BLOCK_WAVES>(KMP_MULTI_ARGS);
 }
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
-__global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
+__global__ void __launch_bounds__(KMP_MULTI_WIDE_WAVES * KMP_WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 kmp_scan_multi_wide_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES, KMP_MULTI_WIDE_WAVES>(KMP_MULTI_ARGS);
 }
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
 kmp_scan_multi_emit_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, true, ONES>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, true, ONES, KMP_MULTI_BLOCK_WAVES>(KMP_MULTI_ARGS);
 }
 
 }  // namespace
 
-/* LDS one block of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
-size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique)
+/* LDS one block of `waves` wavefronts of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
+size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves)
 {
-    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + KMP_MULTI_BLOCK_WAVES * QCAP * 8u) * sizeof(uint32_t);
+    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + waves * QCAP * 8u) * sizeof(uint32_t);
+}
+
+/* Which entry point a fused launch takes (0 counting, 1 wide, 2 with offset records), and how many wavefronts of it a CU
+ * holds at once: what the wavefront plan of the scan is cut for. */
+int kmp_multi_kind(bool emit, bool pad_clean, uint32_t n_ones) { return emit ? 2 : (n_ones != 0u || !pad_clean) ? 1 : 0; }
+uint32_t kmp_multi_block_waves(int kind) { return kind == 1 ? KMP_MULTI_WIDE_WAVES : KMP_MULTI_BLOCK_WAVES; }
+uint32_t kmp_multi_resident_waves(int kind, uint32_t table_words, uint32_t n_unique)
+{
+    const uint32_t bw = kmp_multi_block_waves(kind);
+    const uint32_t by_regs = kind == 0 ? 2u : kind == 1 ? 2u : 1u;                       /* blocks per CU the registers allow */
+    const uint32_t by_lds = (uint32_t)((160u * 1024u) / (kmp_multi_lds_bytes(table_words, n_unique, bw) + 512u));
+    return bw * (by_lds < by_regs ? (by_lds ? by_lds : 1u) : by_regs);
 }
 
 /* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
@@ -495,13 +541,15 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
 {
     if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
-    const size_t lds = kmp_multi_lds_bytes(table_words, n_unique) - (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t);      /* the dynamic part */
+    const int kind = kmp_multi_kind(a.emit_out != nullptr, a.pad_clean, n_ones);
+    const uint32_t bwaves = kmp_multi_block_waves(kind);
+    const size_t lds = kmp_multi_lds_bytes(table_words, n_unique, bwaves) - (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t);      /* the dynamic part */
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
     /* tuning only (tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the kernel after a stage -- 1 = level 1
      * alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  Read once per process. */
     static const uint32_t ablate = []() { const char *e = getenv("KMP_MULTI_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
-#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + KMP_MULTI_BLOCK_WAVES - 1u) / KMP_MULTI_BLOCK_WAVES), \
-        dim3(KMP_MULTI_BLOCK_THREADS), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, \
+#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + bwaves - 1u) / bwaves), \
+        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, \
         a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
         if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \

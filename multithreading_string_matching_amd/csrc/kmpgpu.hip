@@ -132,13 +132,14 @@ bool use_flat(const kmpgpu_ctx *c)
     if (c->kernel_sel == 3) return true;
     return c->kernel_sel == 0 && (c->uni_len >= 512u || !c->packed || !c->d_bitmap);
 }
-/* Fused multi-pattern pass: explicit (1) or automatic (2: from 3 unique eligible patterns on, where it
- * beats one streaming pass per pattern -- profiles/r01_multipattern.txt). */
+/* Fused multi-pattern pass: explicit (1) or automatic (2): from 2 unique eligible patterns on -- 0.24 ms against
+ * 2 x 0.23 ms as streaming passes over 1.5 GB (profiles/r02_multipattern.txt); the 1-byte patterns that ride along
+ * do not count, a set of one eligible pattern plus 1-byte patterns keeps its streaming passes. */
 bool use_fused(const kmpgpu_ctx *c)
 {
     if (!c->packed || !c->d_bitmap || c->mode != 0 || c->kernel_sel == 1 || c->fused_groups.empty()) return false;
     if (c->fused == 1) return c->n_multi_unique >= 2;
-    return c->fused == 2 && c->n_multi_unique >= 3;
+    return c->fused == 2 && c->n_multi_unique >= 2;
 }
 
 bool use_packed(const kmpgpu_ctx *c)
@@ -146,7 +147,7 @@ bool use_packed(const kmpgpu_ctx *c)
     return c->packed && c->d_bitmap && c->mode == 0 && (c->kernel_sel == 2 || ((c->kernel_sel == 0 || c->kernel_sel == 3) && !use_flat(c)));
 }
 
-uint32_t grid_blocks(const kmpgpu_ctx *c)
+uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
 {
     /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat kernel (HBM-bound from 3 on), 6 for
      * the packed kernel (profiles/r01_packed_tuning.txt), 8 for the general one; the fused pass takes what fits a CU
@@ -154,14 +155,13 @@ uint32_t grid_blocks(const kmpgpu_ctx *c)
     const bool streaming = use_flat(c) || use_packed(c);
     int fused_bpc = 7;
     if (use_fused(c)) {
-        /* as many blocks as the CU's 160 KB of LDS hold (the grid is persistent: a block that cannot be resident would
-         * run as a second round) */
-        size_t lds = 1;
-        for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) lds = std::max(lds, kmp_multi_lds_bytes(g.words, g.n_unique));
-        /* (kmp_multi_lds_bytes is what one block of that kernel takes, KMP_MULTI_BLOCK_WAVES wavefronts; this function
-         * counts in 4-wavefront blocks, the unit the plan is cut in; 32 wavefronts per CU is what the counting kernel's 64 VGPRs allow) */
-        const size_t fit = std::max<size_t>(1, std::min<size_t>((160u * 1024u) / (lds + 512u), 32u / KMP_MULTI_BLOCK_WAVES));
-        fused_bpc = (int)std::max<size_t>(1, fit * KMP_MULTI_BLOCK_WAVES / KMP_BLOCK_WAVES);
+        /* as many wavefronts as a CU holds of the kernel the pass will take (registers and the 160 KB of LDS; the grid is
+         * persistent: a block that cannot be resident would run as a second round), counted here in 4-wavefront blocks,
+         * the unit the plan is cut in.  Only the first group carries 1-byte patterns; the plan follows it. */
+        uint32_t waves = 64u;
+        for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups)
+            waves = std::min(waves, kmp_multi_resident_waves(kmp_multi_kind(emit, c->pad_clean, c->fused_groups.front().n_ones), g.words, g.n_unique));
+        fused_bpc = (int)std::max<uint32_t>(1u, waves / KMP_BLOCK_WAVES);
     }
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
                   : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
@@ -289,7 +289,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         if (launches) *launches = 0;
         return KMPGPU_OK;
     }
-    const uint32_t bx = grid_blocks(c);
+    const uint32_t bx = grid_blocks(c, emit != nullptr);
     int rc = ensure_partials(c, (size_t)bx * c->n_pat);
     if (rc) return rc;
 
