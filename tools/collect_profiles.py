@@ -8,8 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, pmc_log = sys.argv[1], sys.argv[2]
 pre = sys.argv[3] if len(sys.argv) > 3 else "r01"
 kt_dir = os.path.join(ROOT, "gpurun_out", "prof", f"{tag}_kt")
-stats = glob.glob(os.path.join(kt_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
-trace = glob.glob(os.path.join(kt_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
+# gpurun merges every call's output into the same local directory: take the newest run
+newest = lambda pat: max(glob.glob(os.path.join(kt_dir, "**", pat), recursive=True), key=os.path.getmtime)
+stats = newest("*kernel_stats.csv")
+trace = newest("*kernel_trace.csv")
 out_stats = os.path.join(ROOT, "profiles", f"{pre}_kernel_stats.csv")
 open(out_stats, "w").write(open(stats).read())
 
