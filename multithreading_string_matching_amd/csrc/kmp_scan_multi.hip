@@ -42,6 +42,12 @@ namespace {
  *     (Round 1 walked every lane's hits chunk by chunk: 2 rounds of ~40 dependent instructions and three LDS round trips
  *     with 7 % of the lanes doing work, 55 % of the kernel's time.)
  * ============================================================================================== */
+/* tuning builds (-DKMP_MULTI_TUNING): cut the kernel after stage n_ (a scalar branch); nothing in the product build */
+#ifdef KMP_MULTI_TUNING
+#define KMP_MULTI_CUT(n_, stmt_) do { if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == (n_)) { stmt_; } } } while (0)
+#else
+#define KMP_MULTI_CUT(n_, stmt_) do { (void)ablate; } while (0)
+#endif
 constexpr uint32_t QCAP = 80u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
 constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a time */
 
@@ -342,7 +348,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                         hmq[q4 >> 1] = __builtin_amdgcn_udot4(hb & 0x01010101u, (q4 & 1) ? 0x80402010u : 0x08040201u, hmq[q4 >> 1], false);
                     }
                     uint32_t hm = hmq[0] | (hmq[1] << 8);
-                    if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == 1u) hm = 0u; }      /* tuning switch: a scalar branch, not a select per chunk */
+                    KMP_MULTI_CUT(1u, hm = 0u);
                     if (ONES || ballot64(hm != 0u) != 0ull) {
                         /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
                          * and no 0x00 before them (strlen rule, serial.c:191).  Nearly every 0x00 of real traffic and all of the
@@ -424,7 +430,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                             }
                         }
                         if (ballot64(nl < 15) != 0ull) hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
-                        if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == 2u) hm = 0u; }
+                        KMP_MULTI_CUT(2u, hm = 0u);
                         const uint64_t hl_ = ballot64(hm != 0u);                    /* the lanes that have a hit */
                         if (hl_ != 0ull) {
                             /* append one record per such lane to the queue */
@@ -438,7 +444,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                                 q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), cb + vo0);
                             }
                             q_count += nnew;
-                            if (ablate != 0u) { asm volatile("" ::: "memory"); if (ablate == 3u) { q_head = 0u; q_count = 0u; } }
+                            KMP_MULTI_CUT(3u, (q_head = 0u, q_count = 0u));
                             if constexpr (EMIT) {
                                 e_st = st;
                                 while (q_count != 0u) process_batch(min(q_count, 64u));
@@ -545,9 +551,14 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const uint32_t bwaves = kmp_multi_block_waves(kind);
     const size_t lds = kmp_multi_lds_bytes(table_words, n_unique, bwaves) - (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t);      /* the dynamic part */
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
-    /* tuning only (tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the kernel after a stage -- 1 = level 1
-     * alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  Read once per process. */
+    /* tuning builds only (make HIPFLAGS+=-DKMP_MULTI_TUNING; tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the
+     * kernel after a stage -- 1 = level 1 alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  The product
+     * build passes the constant 0. */
+#ifdef KMP_MULTI_TUNING
     static const uint32_t ablate = []() { const char *e = getenv("KMP_MULTI_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
+#else
+    const uint32_t ablate = 0u;
+#endif
 #define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + bwaves - 1u) / bwaves), \
         dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, \
         a.partials, em, uid_first, uid_ids, a.patterns)

@@ -1,4 +1,7 @@
-"""Tuning only: the fused multi-pattern pass cut after each of its stages (KMP_MULTI_ABLATE=1..3), strings.txt and its 3+ / 4+ byte subsets, blocks per CU."""
+"""Tuning only: the fused multi-pattern pass cut after each of its stages (KMP_MULTI_ABLATE=1..3), strings.txt and its 3+ / 4+ byte subsets, blocks per CU.
+The stage switch exists in tuning builds of the library only:
+    make -C multithreading_string_matching_amd/csrc clean all HIPFLAGS_EXTRA=-DKMP_MULTI_TUNING
+(rebuild without it afterwards; the product build ignores KMP_MULTI_ABLATE)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
