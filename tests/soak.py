@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Differential soak (not part of the test suite): random payload sets and pattern sets through every kernel
+"""Differential soak (under tests/ because it drives the oracle; not collected by pytest): random payload sets and pattern sets through every kernel
 variant against the CPU oracle, for a given number of seconds.  Also compares emitted offsets on a subset.
-Usage: tools/soak.py [seconds] [first_seed]"""
+Usage: tests/soak.py [seconds] [first_seed]"""
 import os, random, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
