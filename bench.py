@@ -431,10 +431,17 @@ def main() -> None:
 
     # ---- the other BASELINE configs, after the timed headline region (rank 0, N == 1) -----------------
     extra = None
+    extra_error = None
     if rank == 0 and world == 1 and not args.no_extra:
         headline = (d_arena, d_off, d_len, n, PAYLOAD_LEN)
         del d_arena, d_off, d_len
-        extra = extra_configs(m, dev, args.extra_passes, headline, sample97)
+        # a failing leg (a count check included) must not cost the headline line, which has been measured and checked by now:
+        # it is reported in the JSON ("extra_configs_error") and on stderr instead
+        try:
+            extra = extra_configs(m, dev, args.extra_passes, headline, sample97)
+        except (SystemExit, Exception) as e:          # noqa: BLE001 -- SystemExit is how the legs report a count mismatch
+            extra_error = f"{type(e).__name__}: {e}"
+            log(f"extra_configs FAILED: {extra_error}")
         del headline
 
     if rank == 0:
@@ -474,6 +481,7 @@ def main() -> None:
             },
             "cpu_baseline": cpu,
             "extra_configs": extra,
+            **({"extra_configs_error": extra_error} if extra_error else {}),
         }
         print(json.dumps(out), flush=True)
 
