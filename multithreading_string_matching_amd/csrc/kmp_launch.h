@@ -43,7 +43,8 @@ hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uin
                            void *plan, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr,
-                             int accumulate = 0);
+                             int accumulate = 0, unsigned long long *scratch = nullptr, uint32_t *tickets = nullptr);
+#define KMP_REDUCE_SCRATCH_WORDS 64u      /* per pattern of a launch: kmp_reduce_kernel's slice sums (KMP_REDUCE_MAX_SLICES) */
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st);
 size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves);

@@ -173,27 +173,59 @@ kmp_gather_kernel(const uint8_t *__restrict__ file, const uint64_t *__restrict__
     }
 }
 
-/* counts[pat_ids[y]] = sum of that pattern's block partials. */
-__global__ void __launch_bounds__(KMP_BLOCK_THREADS)
+/* counts[pat_ids[y]] = sum of that pattern's block partials.  The persistent grids leave a thousand partials or two per
+ * pattern: one 256-thread block each.  The flat kernel's grid is one block per 16 packets -- 62 500 partials per million
+ * packets, 500 000 for an 8 M-packet shard -- which one block would take 60 us to add up: the row is cut into gridDim.y
+ * slices, every slice block leaves its sum in `scratch` and takes a ticket, and the block that draws the last ticket adds the
+ * slice sums up, writes the count and puts the ticket counter back to 0 for the next pass. */
+#define KMP_REDUCE_THREADS 1024u
+#define KMP_REDUCE_MAX_SLICES 64u
+__global__ void __launch_bounds__(KMP_REDUCE_THREADS)
 kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t blocks_x,
                   const uint32_t *__restrict__ pat_ids, const uint32_t *__restrict__ rows,
-                  unsigned long long *__restrict__ counts, int accumulate)
+                  unsigned long long *__restrict__ counts, int accumulate, unsigned long long *__restrict__ scratch,
+                  uint32_t *__restrict__ tickets)
 {
-    __shared__ unsigned long long s[KMP_BLOCK_WAVES];
+    __shared__ unsigned long long s[KMP_REDUCE_THREADS / KMP_WAVE];
     unsigned long long t = 0ull;
     /* rows == nullptr: row y of partials belongs to pat_ids[y]; else row rows[y] (fused pass: duplicates share a row) */
     const unsigned long long *row = partials + (uint64_t)(rows ? rows[blockIdx.x] : blockIdx.x) * blocks_x;
-    for (uint32_t i = threadIdx.x; i < blocks_x; i += KMP_BLOCK_THREADS) t += row[i];
+    const uint32_t slices = gridDim.y;
+    const uint32_t per = (blocks_x + slices - 1u) / slices;
+    const uint32_t lo = blockIdx.y * per, hi = min(blocks_x, lo + per);
+    uint32_t i = lo + threadIdx.x;
+    for (; i + 7u * blockDim.x < hi; i += 8u * blockDim.x) {                 /* eight loads in flight per thread */
+        unsigned long long v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) v[u] = row[i + u * blockDim.x];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) t += v[u];
+    }
+    for (; i < hi; i += blockDim.x) t += row[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if ((threadIdx.x & 63u) == 0u) s[threadIdx.x >> 6] = t;
     __syncthreads();
     if (threadIdx.x == 0u) {
         unsigned long long r = 0ull;
-        for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) r += s[i];
-        /* accumulate: counts keep adding up over the batches of a streamed capture (openmp_task.c:172-175) */
-        unsigned long long *dst = counts + pat_ids[blockIdx.x];
-        *dst = accumulate ? *dst + r : r;
+        for (uint32_t w = 0; w < blockDim.x / KMP_WAVE; ++w) r += s[w];
+        bool last = true;
+        if (slices > 1u) {
+            __hip_atomic_store(&scratch[(uint64_t)blockIdx.x * KMP_REDUCE_MAX_SLICES + blockIdx.y], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t ticket = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last = ticket == slices - 1u;
+            if (last) {
+                r = 0ull;
+                for (uint32_t k = 0; k < slices; ++k)
+                    r += __hip_atomic_load(&scratch[(uint64_t)blockIdx.x * KMP_REDUCE_MAX_SLICES + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (last) {
+            /* accumulate: counts keep adding up over the batches of a streamed capture (openmp_task.c:172-175) */
+            unsigned long long *dst = counts + pat_ids[blockIdx.x];
+            *dst = accumulate ? *dst + r : r;
+        }
     }
 }
 
@@ -345,11 +377,15 @@ hipError_t kmp_launch_repack_phase2(const uint8_t *old_arena, const uint64_t *ol
 }
 
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
-                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows, int accumulate)
+                             uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows, int accumulate,
+                             unsigned long long *scratch, uint32_t *tickets)
 {
     if (n_ids == 0) return hipSuccess;
-    hipLaunchKernelGGL(kmp_reduce_kernel, dim3(n_ids), dim3(KMP_BLOCK_THREADS), 0, st, partials, blocks_x, pat_ids, rows, counts,
-                       accumulate);
+    /* one slice per 8192 partials when the caller has the scratch for it (n_ids x KMP_REDUCE_MAX_SLICES words, n_ids tickets at 0) */
+    uint32_t slices = 1u;
+    if (scratch && tickets && blocks_x > 16384u) slices = std::min<uint32_t>(KMP_REDUCE_MAX_SLICES, (blocks_x + 8191u) / 8192u);
+    hipLaunchKernelGGL(kmp_reduce_kernel, dim3(n_ids, slices), dim3(blocks_x > 8192u ? KMP_REDUCE_THREADS : KMP_BLOCK_THREADS), 0, st, partials, blocks_x,
+                       pat_ids, rows, counts, accumulate, scratch, tickets);
     return hipGetLastError();
 }
 

@@ -83,6 +83,8 @@ struct kmpgpu_ctx {
     std::vector<FusedGroup> fused_groups;
     uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
     uint32_t             *d_rest_ids = nullptr;      /* [rest_long + rest_short] everything else, long first  */
+    unsigned long long   *d_red_scratch = nullptr;   /* [n_pat][KMP_REDUCE_SCRATCH_WORDS] slice sums of the two-level count reduce */
+    uint32_t             *d_red_tickets = nullptr;   /* [n_pat] its ticket counters, 0 between launches         */
     uint32_t              rest_long = 0, rest_short = 0;
 
     /* arena */
@@ -166,6 +168,21 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
                   : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
     uint64_t need = (c->n_pkts + KMP_BLOCK_WAVES - 1) / KMP_BLOCK_WAVES;
+    if (c->blocks_per_cu <= 0 && use_flat(c) && !use_fused(c) && c->uni_stride) {
+        /* The flat kernel does NOT run as a persistent grid: a wavefront takes ~6 KiB (four 1500-byte packets) and the grid is
+         * one block per four such ranges.  The hardware hands the blocks out in order as CUs free up, so at any moment the
+         * whole chip reads one compact, moving window of the arena and nobody waits for a straggler at the end: 209-211 us per
+         * 1.5 GB (0.89 of the HBM peak) against 223-234 us with four resident blocks per CU and 366 KB per wavefront
+         * (profiles/r02_flat_grid.txt).  Capped so that the partial counts stay below 2^24 entries. */
+        uint64_t g = c->uni_stride, r = 128;
+        while (r) { const uint64_t t = g % r; g = r; r = t; }                     /* gcd(stride, 128): ranges start on 128-byte lines */
+        const uint64_t q = 128 / g;
+        const uint64_t ppw = std::max<uint64_t>(6144 / c->uni_stride / q * q, q);        /* about 6 KiB, a multiple of q packets (1504-byte slots: 4) */
+        uint64_t bx = (c->n_pkts + KMP_BLOCK_WAVES * ppw - 1) / (KMP_BLOCK_WAVES * ppw);
+        const uint64_t max_bx = std::max<uint64_t>((1ull << 24) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 4u);
+        bx = std::min(bx, max_bx);
+        return (uint32_t)std::max<uint64_t>(bx, 1);
+    }
     if (streaming && c->blocks_per_cu <= 0) {
         /* small captures: give every wavefront at least 8 KiB to stream instead of launching
          * thousands of nearly empty wavefronts per pattern */
@@ -361,7 +378,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             HIP_TRY(record(e0, e1));
             HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-            HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate));
+            HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate, c->d_red_scratch, c->d_red_tickets));
             ++nl;
             max_u = std::max(max_u, g.n_unique);
         }
@@ -384,7 +401,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
                 return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: the arena could not be brought into the streaming kernels' layout");
             HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream, nullptr, c->accumulate));
+            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream, nullptr, c->accumulate, c->d_red_scratch, c->d_red_tickets));
             ++nl;
         }
     }
@@ -451,6 +468,8 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_plan) (void)hipFree(c->d_plan);
     free_fused_groups(c);
     if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
+    if (c->d_red_scratch) (void)hipFree(c->d_red_scratch);
+    if (c->d_red_tickets) (void)hipFree(c->d_red_tickets);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -475,7 +494,7 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
         if (value != 0 && value != 1) return fail(KMPGPU_EINVAL, "mode must be 0 or 1");
         c->mode = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_BLOCKS_PER_CU:
-        if (value < 0 || value > 64) return fail(KMPGPU_EINVAL, "blocks per CU must be 0 (auto) or 1..64");
+        if (value < 0 || value > 256) return fail(KMPGPU_EINVAL, "blocks per CU must be 0 (auto) or 1..256");
         c->blocks_per_cu = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_DEPTH:
         if (value != 0 && (value < 2 || value > 8 || value == 7)) return fail(KMPGPU_EINVAL, "depth must be 0 (auto), 2..6 or 8");
@@ -534,12 +553,17 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     if (c->d_patterns) { HIP_TRY(hipFree(c->d_patterns)); c->d_patterns = nullptr; }
     if (c->d_ids) { HIP_TRY(hipFree(c->d_ids)); c->d_ids = nullptr; }
     if (c->d_counts) { HIP_TRY(hipFree(c->d_counts)); c->d_counts = nullptr; }
+    if (c->d_red_scratch) { HIP_TRY(hipFree(c->d_red_scratch)); c->d_red_scratch = nullptr; }
+    if (c->d_red_tickets) { HIP_TRY(hipFree(c->d_red_tickets)); c->d_red_tickets = nullptr; }
     c->n_pat = n_pat; c->n_long = (uint32_t)ids_long.size(); c->n_short = (uint32_t)ids_short.size();
     const size_t np = n_pat ? n_pat : 1;
     HIP_TRY(hipMalloc(&c->d_patterns, np * sizeof(kmp_pattern_dev)));
     HIP_TRY(hipMalloc(&c->d_ids, np * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->d_counts, np * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_counts, 0, np * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_red_scratch, np * KMP_REDUCE_SCRATCH_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_red_tickets, np * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->d_red_tickets, 0, np * sizeof(uint32_t)));
     if (n_pat) {
         std::vector<uint32_t> ids(ids_long);
         ids.insert(ids.end(), ids_short.begin(), ids_short.end());
