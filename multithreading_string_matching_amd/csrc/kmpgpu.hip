@@ -163,7 +163,8 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
         uint32_t waves = 64u;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups)
             waves = std::min(waves, kmp_multi_resident_waves(kmp_multi_kind(emit, c->pad_clean, c->fused_groups.front().n_ones), g.words, g.n_unique));
-        fused_bpc = (int)std::max<uint32_t>(1u, waves / KMP_BLOCK_WAVES);
+        /* twice that: the second half of the blocks starts as the first ones finish, which evens out the ragged end (325 -> 317 us) */
+        fused_bpc = (int)std::max<uint32_t>(1u, 2u * waves / KMP_BLOCK_WAVES);
     }
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
                   : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
@@ -181,6 +182,16 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
         uint64_t bx = (c->n_pkts + KMP_BLOCK_WAVES * ppw - 1) / (KMP_BLOCK_WAVES * ppw);
         const uint64_t max_bx = std::max<uint64_t>((1ull << 24) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 4u);
         bx = std::min(bx, max_bx);
+        return (uint32_t)std::max<uint64_t>(bx, 1);
+    }
+    if (c->blocks_per_cu <= 0 && use_packed(c) && !use_fused(c)) {
+        /* The packed kernel likewise: ~16 KiB per wavefront and as many blocks as that takes, handed out in order by the
+         * hardware (its per-range set-up -- plan entry, bitmap words -- is heavier than the flat kernel's, 6 KiB ranges cost
+         * more than they gain): Zipf 64..9000 B 109 -> 105 us per 0.67 GB, 64-byte payloads 155 -> 143 us per 0.77 GB
+         * (profiles/r02_flat_grid.txt). */
+        const uint64_t span = c->span_end - c->uni_off0;
+        uint64_t bx = std::min<uint64_t>(need, (span + KMP_BLOCK_WAVES * 16384ull - 1) / (KMP_BLOCK_WAVES * 16384ull));
+        bx = std::min<uint64_t>(bx, std::max<uint64_t>((1ull << 24) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 6u));
         return (uint32_t)std::max<uint64_t>(bx, 1);
     }
     if (streaming && c->blocks_per_cu <= 0) {

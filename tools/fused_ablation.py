@@ -17,7 +17,7 @@ torch.cuda.synchronize(); m.fixed_index(d_off, d_len, L, 16); m.synth_fill(d_are
 m.set_option(OPT_FUSED, 1)
 for name, pp in (("97", pats), ("97 + e, t", pats + [b"e", b"t"]), ("3+ bytes only", [p for p in pats if len(p) >= 3]), ("4+ bytes only", [p for p in pats if len(p) >= 4])):
     m.set_patterns(pp); m.attach_arena(d_arena, d_off, d_len)
-    for bpc in (0, 4, 8):
+    for bpc in (0, 4, 8, 16, 32):
         m.set_option(OPT_BLOCKS_PER_CU, bpc)
         for _ in range(120 if bpc == 0 else 20): m.scan_enqueue()      # the first configuration also warms the clocks up
         m.sync()
