@@ -63,7 +63,8 @@ typedef struct kmpgpu_match {
 
 /* Option keys for kmpgpu_set_option. */
 #define KMPGPU_OPT_MODE          1   /* 0 auto (filter + KMP verify), 1 KMP automaton only */
-#define KMPGPU_OPT_BLOCKS_PER_CU 2   /* persistent grid = CUs * this; 0 = auto (default)    */
+#define KMPGPU_OPT_BLOCKS_PER_CU 2   /* grid = CUs * this (1..256); 0 = auto (default): the streaming kernels
+                                        take ~6-16 KiB per wavefront, however many blocks that is */
 #define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8; 0 = auto */
 #define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: the patterns of 2..99
                                         bytes are counted in ONE read of a packed arena per 256

@@ -5,24 +5,27 @@
  * (byte scan, HBM-bound).
  *
  * Shape of the streaming kernels (flat: uniform stride, packed: any lengths)
- *   - a persistent grid; every wavefront owns ONE contiguous byte range of the arena (whole packets) and
- *     streams it in 1 KiB chunks: one buffer_load_dwordx4 per lane (16 B), perfectly coalesced, DEPTH
- *     chunk loads in flight per wavefront in a register ring driven by hand-counted s_waitcnt vmcnt(N)
- *     (kmp_dev_common.h: ring_wait / flat_issue); the buffer resource's record count makes the tail
- *     chunk read zeros, so there is no clamping and no lane mask;
+ *   - every wavefront owns ONE contiguous byte range of the arena (whole packets) and streams it in 1 KiB chunks: one
+ *     buffer_load_dwordx4 per lane (16 B), perfectly coalesced, DEPTH chunk loads in flight per wavefront in a register
+ *     ring driven by hand-counted s_waitcnt vmcnt(N) (kmp_dev_common.h: ring_wait / flat_issue); the buffer resource's
+ *     record count makes the tail chunk read zeros, so there is no clamping and no lane mask;
+ *   - the ranges are SMALL and the grid is not persistent: ~6 KiB per wavefront for the flat kernel (four 1500-byte
+ *     packets), ~16 KiB for the packed one, one block per four ranges, handed out in arena order by the hardware as CUs
+ *     free up -- the whole chip reads one compact moving window of the arena (kmpgpu.hip grid_blocks,
+ *     profiles/r02_flat_grid.txt: 0.89 of the HBM peak against 0.82 with one long resident range per wavefront);
  *   - still one packet per wavefront at a time: the packets of a range are scanned in order by the same
  *     wavefront, which keeps the strlen() rule (serial.c:191) wave-local state;
- *   - per chunk, every lane tests its 16 start offsets with a 4-byte compare against the pattern's first
- *     dword (halo dword from the next lane by DPP wave_shl:1), reduced with v_min3 per group of four
- *     offsets, and looks for 0x00 bytes with the has-zero trick; three ballots (zero lanes, packet-start
- *     lanes, candidate lanes); the common case -- no candidate in the chunk -- ends there;
- *   - rare path: per lane the largest start index that still counts (window inside the payload, no 0x00
- *     before it); patterns of <= 4 bytes are exact after the filter, 5..20 bytes with few candidate lanes
- *     are compared dword-wise from registers, everything else runs the KMP automaton (pattern + failure
- *     table in LDS, text bytes from registers) -- the literal kmp_matcher (serial.c:190-215);
+ *   - per chunk, every lane tests its 16 start offsets against the pattern's first dword with four v_mqsad_pk_u16_u8
+ *     (masked quad byte-SAD: four offsets per instruction, byte alignment included; halo dword from the next lane by
+ *     DPP wave_shl:1) and looks for 0x00 bytes with the has-zero trick; three ballots (zero lanes, packet-start lanes,
+ *     candidate lanes); the common case -- no candidate in the chunk -- ends there;
+ *   - rare path (confirm_sad, kmp_dev_common.h): every start offset of every candidate lane is compared in full,
+ *     branch-free, by accumulating the pattern's further dwords into the filter's sums (16 bytes per block, further
+ *     blocks by scalar loads); per lane the largest start index that still counts (window inside the payload, no 0x00
+ *     before it) bars the rest.  The literal KMP automaton (kmp_matcher, serial.c:190-215) lives in kmp_scan_general.hip;
  *   - a start offset s counts iff s + m <= E, E = min(len, first 0x00);
  *   - counts: per-lane -> wave -> block, one partial per (block, pattern), summed by kmp_reduce_kernel
- *     (no atomics, deterministic).
+ *     (plain stores, deterministic).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

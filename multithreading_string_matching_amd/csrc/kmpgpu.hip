@@ -151,14 +151,14 @@ bool use_packed(const kmpgpu_ctx *c)
 
 uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
 {
-    /* persistent grid: measured best on MI355X is 4 blocks/CU for the flat kernel (HBM-bound from 3 on), 6 for
-     * the packed kernel (profiles/r01_packed_tuning.txt), 8 for the general one; the fused pass takes what fits a CU
-     * (two of its 16-wavefront blocks = 8 of this function's 4-wavefront units, see below) */
+    /* In units of 4-wavefront blocks.  An explicit KMPGPU_OPT_BLOCKS_PER_CU means CUs x that many (the shape of rounds 1-2:
+     * a persistent grid, 4 per CU for the flat kernel, 6 for the packed one); automatic: the flat and the packed kernel
+     * take small ranges and as many blocks as that needs (below), the general kernel 8 per CU, the fused pass twice what
+     * fits a CU (two of its 16-wavefront blocks = 8 of these units). */
     const bool streaming = use_flat(c) || use_packed(c);
     int fused_bpc = 7;
     if (use_fused(c)) {
-        /* as many wavefronts as a CU holds of the kernel the pass will take (registers and the 160 KB of LDS; the grid is
-         * persistent: a block that cannot be resident would run as a second round), counted here in 4-wavefront blocks,
+        /* as many wavefronts as a CU holds of the kernel the pass will take (registers and the 160 KB of LDS), counted here in 4-wavefront blocks,
          * the unit the plan is cut in.  Only the first group carries 1-byte patterns; the plan follows it. */
         uint32_t waves = 64u;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups)
