@@ -381,9 +381,9 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
                              unsigned long long *scratch, uint32_t *tickets)
 {
     if (n_ids == 0) return hipSuccess;
-    /* one slice per 8192 partials when the caller has the scratch for it (n_ids x KMP_REDUCE_MAX_SLICES words, n_ids tickets at 0) */
+    /* one slice per 4096 partials when the caller has the scratch for it (n_ids x KMP_REDUCE_MAX_SLICES words, n_ids tickets at 0) */
     uint32_t slices = 1u;
-    if (scratch && tickets && blocks_x > 16384u) slices = std::min<uint32_t>(KMP_REDUCE_MAX_SLICES, (blocks_x + 8191u) / 8192u);
+    if (scratch && tickets && blocks_x > 16384u) slices = std::min<uint32_t>(KMP_REDUCE_MAX_SLICES, (blocks_x + 4095u) / 4096u);
     hipLaunchKernelGGL(kmp_reduce_kernel, dim3(n_ids, slices), dim3(blocks_x > 8192u ? KMP_REDUCE_THREADS : KMP_BLOCK_THREADS), 0, st, partials, blocks_x,
                        pat_ids, rows, counts, accumulate, scratch, tickets);
     return hipGetLastError();
