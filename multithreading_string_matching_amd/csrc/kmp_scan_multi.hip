@@ -536,7 +536,7 @@ uint32_t kmp_multi_block_waves(int kind) { return kind == 1 ? KMP_MULTI_WIDE_WAV
 uint32_t kmp_multi_resident_waves(int kind, uint32_t table_words, uint32_t n_unique)
 {
     const uint32_t bw = kmp_multi_block_waves(kind);
-    const uint32_t by_regs = kind == 0 ? 2u : kind == 1 ? 2u : 1u;                       /* blocks per CU the registers allow */
+    const uint32_t by_regs = (kind == 0 ? 32u : kind == 1 ? 24u : 16u) / bw;             /* blocks per CU the registers allow: 8 / 6 / 4 wavefronts per SIMD */
     const uint32_t by_lds = (uint32_t)((160u * 1024u) / (kmp_multi_lds_bytes(table_words, n_unique, bw) + 512u));
     return bw * (by_lds < by_regs ? (by_lds ? by_lds : 1u) : by_regs);
 }
