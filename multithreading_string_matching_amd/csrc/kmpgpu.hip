@@ -177,7 +177,7 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
          * (profiles/r02_flat_grid.txt).  Capped so that the partial counts stay below 2^24 entries. */
         uint64_t g = c->uni_stride, r = 128;
         while (r) { const uint64_t t = g % r; g = r; r = t; }                     /* gcd(stride, 128): ranges start on 128-byte lines */
-        const uint64_t q = 128 / g;
+        const uint64_t q = c->uni_stride >= 4096u ? 1 : 128 / g;                  /* (long payloads: a shared line per range is noise, a range of several is not) */
         const uint64_t ppw = std::max<uint64_t>(6144 / c->uni_stride / q * q, q);        /* about 6 KiB, a multiple of q packets (1504-byte slots: 4) */
         uint64_t bx = (c->n_pkts + KMP_BLOCK_WAVES * ppw - 1) / (KMP_BLOCK_WAVES * ppw);
         const uint64_t max_bx = std::max<uint64_t>((1ull << 24) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 4u);
@@ -334,7 +334,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         /* start every wavefront's range on a 128-byte line so that neighbouring ranges share no cache line */
         uint64_t g = c->uni_stride, r = 128;
         while (r) { const uint64_t t = g % r; g = r; r = t; }      /* gcd(stride, 128) */
-        const uint64_t q = 128 / g;
+        const uint64_t q = c->uni_stride >= 4096u ? 1 : 128 / g;
         ppw = (ppw + q - 1) / q * q;
     }
     const bool flat = use_flat(c) && ppw * c->uni_stride < (1ull << 31);
