@@ -174,13 +174,13 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
          * one block per four such ranges.  The hardware hands the blocks out in order as CUs free up, so at any moment the
          * whole chip reads one compact, moving window of the arena and nobody waits for a straggler at the end: 209-211 us per
          * 1.5 GB (0.89 of the HBM peak) against 223-234 us with four resident blocks per CU and 366 KB per wavefront
-         * (profiles/r02_flat_grid.txt).  Capped so that the partial counts stay below 2^24 entries. */
+         * (profiles/r02_flat_grid.txt).  Capped so that blocks x patterns stays below 2^22 (partial counts; a launch of 2^30 threads). */
         uint64_t g = c->uni_stride, r = 128;
         while (r) { const uint64_t t = g % r; g = r; r = t; }                     /* gcd(stride, 128): ranges start on 128-byte lines */
         const uint64_t q = c->uni_stride >= 4096u ? 1 : 128 / g;                  /* (long payloads: a shared line per range is noise, a range of several is not) */
         const uint64_t ppw = std::max<uint64_t>(6144 / c->uni_stride / q * q, q);        /* about 6 KiB, a multiple of q packets (1504-byte slots: 4) */
         uint64_t bx = (c->n_pkts + KMP_BLOCK_WAVES * ppw - 1) / (KMP_BLOCK_WAVES * ppw);
-        const uint64_t max_bx = std::max<uint64_t>((1ull << 24) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 4u);
+        const uint64_t max_bx = std::max<uint64_t>((1ull << 22) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 4u);
         bx = std::min(bx, max_bx);
         return (uint32_t)std::max<uint64_t>(bx, 1);
     }
@@ -191,7 +191,7 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
          * (profiles/r02_flat_grid.txt). */
         const uint64_t span = c->span_end - c->uni_off0;
         uint64_t bx = std::min<uint64_t>(need, (span + KMP_BLOCK_WAVES * 16384ull - 1) / (KMP_BLOCK_WAVES * 16384ull));
-        bx = std::min<uint64_t>(bx, std::max<uint64_t>((1ull << 24) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 6u));
+        bx = std::min<uint64_t>(bx, std::max<uint64_t>((1ull << 22) / std::max<uint32_t>(c->n_pat, 1u), (uint64_t)c->cu_count * 6u));
         return (uint32_t)std::max<uint64_t>(bx, 1);
     }
     if (streaming && c->blocks_per_cu <= 0) {
