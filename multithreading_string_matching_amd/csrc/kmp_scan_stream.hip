@@ -416,10 +416,10 @@ hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
 hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st)
 {
     if (a.n_ids == 0 || a.blocks_x == 0) return hipSuccess;
-    switch (a.depth) {          /* 0 = auto: 3 chunks in flight measured best here (profiles/r01_packed_tuning.txt) */
-    case 4: case 5: return launch_packed_t<4>(a, st);
+    switch (a.depth) {          /* 0 = auto: 4 chunks in flight with the 16 KiB ranges (profiles/r02_flat_grid.txt; 3 with the persistent grid of round 1) */
+    case 2: case 3: return launch_packed_t<3>(a, st);
     case 6: case 8: return launch_packed_t<6>(a, st);
-    default: return launch_packed_t<3>(a, st);
+    default: return launch_packed_t<4>(a, st);
     }
 }
 
