@@ -62,6 +62,38 @@ def host_cores() -> int:
     return n
 
 
+def cpu_model() -> str:
+    """'model name' of the host CPU (print nproc and the CPU model beside the CPU figure)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    (mpirun -np N of mpi_dumping.c:29-31).  This parent never touches the GPU (no torch import, no HIP call): the ranks
+    are fresh child processes, their stdout -- rank 0's ONE JSON line -- is ours, and their exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"bench.py: WORLD_SIZE is not set; starting {n_gpus} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def extra_configs(m, dev, passes, headline, sample97):
     """The other BASELINE configs and the rows VERDICT asks to see through a driver-timed command: each leg is
     count-checked first, then `passes` back-to-back passes are timed with HIP events around the scan launches
@@ -244,6 +276,9 @@ def main() -> None:
                     "the multi-rank code path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))          # before anything touches the GPU
+
     import torch
     import torch.distributed as dist
 
@@ -255,8 +290,6 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
@@ -394,7 +427,7 @@ def main() -> None:
         if int(c1[0]) != K.synth_count_planted(sp, n1, PAYLOAD_LEN, first_pkt_id=first_id):
             raise SystemExit("oracle serial count differs from the planted count")
         cpu = {
-            "value": round(payload_bytes / best / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "value": round(payload_bytes / best / 1e9, 3), "unit": "GB/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "serial_1thread_GBps": round(n1 * PAYLOAD_LEN / t1 / 1e9, 3),
             "sample": f"the full per-GPU workload ({n} x {PAYLOAD_LEN} B, 1 pattern), best of {max(1, args.cpu_reps)} passes, "
                       f"openmp_data.c:126-178 bracket, {best:.3f} s per pass",
@@ -466,6 +499,8 @@ def main() -> None:
                 "packets_per_gpu": n, "payload_len": PAYLOAD_LEN, "patterns": 1, "pattern_len": len(NEEDLE),
                 "parallelism": f"packets sharded over {world} GPU(s), all-reduce(SUM) of counts",
             },
+            "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0,
+            "backend": (("rccl (torch.distributed nccl)" if args.backend == "nccl" else args.backend) if use_dist else "none (one rank)"),
             "matches_per_s": round(total * args.steps / elapsed, 1),
             "matches_per_pass": total,
             "pct_hbm_peak_per_gpu": round(100.0 * value / world / HBM_PEAK_GBS, 2),
@@ -488,6 +523,8 @@ def main() -> None:
     m.close()
     if use_dist:
         dist.destroy_process_group()
+    if extra_error:
+        sys.exit(3)          # the headline line is out; a failed count check of an extra leg still turns the run red
 
 
 if __name__ == "__main__":

@@ -121,7 +121,13 @@ int  kmpgpu_set_patterns(kmpgpu_ctx *ctx, const uint8_t *const *pat, const uint3
  * payload, also an empty one, owns at least one readable 16-byte slot.  The bytes between a payload's
  * end and the end of its slot may hold anything; when they are 0x00 (as kmp_arena builds them -- checked
  * at load time, and cleared in the copy kmpgpu_load_arena makes) the streaming kernels take a payload's
- * end from the packet-start bitmap and never read the index on the scan path. */
+ * end from the packet-start bitmap and never read the index on the scan path.
+ * BEHIND THE LAST SLOT nothing is required: arena_bytes need only reach the end of the last slot
+ * (pkt_off[k] + max(16, round_up(pkt_len[k], 16)) of the payload that lies last), no kernel reads a byte at or
+ * behind that end, and whatever a caller keeps there -- the rest of a larger buffer of which the index is a
+ * prefix view, a longer batch loaded earlier into the same device buffers -- never enters a count: a window
+ * never leaves its payload (serial.c:193,198).  (The host library still leaves KMP_ARENA_SLACK zero bytes
+ * there; the kernels do not depend on them.) */
 int  kmpgpu_load_arena(kmpgpu_ctx *ctx, const uint8_t *arena, uint64_t arena_bytes,
                        const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n_pkts);
 
@@ -185,6 +191,12 @@ int  kmpgpu_comm_init(kmpgpu_comm **comm, kmpgpu_ctx *const *ctx, int n_ctx);
 int  kmpgpu_comm_unique_id(void *id_out);
 int  kmpgpu_comm_init_rank(kmpgpu_comm **comm, kmpgpu_ctx *ctx, int n_ranks, int rank, const void *unique_id);
 int  kmpgpu_comm_allreduce_counts(kmpgpu_comm *comm);
+/* Lifetime: destroy the communicator BEFORE its contexts.  The other order is tolerated -- kmpgpu_destroy() of a context
+ * that is still a rank waits for its stream and detaches it: kmpgpu_comm_allreduce_counts then fails with KMPGPU_ESTATE
+ * and kmpgpu_comm_destroy only releases the RCCL handles -- but the peers of a detached rank must not enter another
+ * collective.  A context belongs to at most one communicator.  Threads: kmpgpu_comm_init_rank may be called from one
+ * thread per context at the same time (it blocks until every rank has joined); calls on ONE communicator are not
+ * thread-safe.  While a communicator is being created the process's stdout (fd 1) points at stderr (RCCL's banner). */
 void kmpgpu_comm_destroy(kmpgpu_comm *comm);
 /* The device a context was created on. */
 int  kmpgpu_device_of(kmpgpu_ctx *ctx);

@@ -246,8 +246,11 @@ int main(int argc, char *argv[])
         kmpgpu_ctx **ctxs = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *ctxs);
         for (int r = 0; r < shards; r++) ctxs[r] = job[r].ctx;
         if (shards <= ndev && (shards > 1 || (rccl_env && rccl_env[0] == '1')) && !(rccl_env && rccl_env[0] == '0')) {
-            if (kmpgpu_comm_init(&comm, ctxs, shards)) die_gpu("kmpgpu_comm_init");
-            reduce_rccl = 1;
+            /* no communicator is no reason to stop: the shards' own counters are summed on the host instead (below) */
+            if (kmpgpu_comm_init(&comm, ctxs, shards)) {
+                fprintf(stderr, "[kmpgpu] kmpgpu_comm_init: %s -- summing the shards' counts on the host\n", kmpgpu_last_error());
+                comm = NULL;
+            } else reduce_rccl = 1;
         }
         const double t_scan0 = now_s();
         /* every shard's pass is enqueued before any result is read, so the GPUs work side by side
@@ -255,15 +258,23 @@ int main(int argc, char *argv[])
         for (int r = 0; r < shards; r++)
             if (kmpgpu_scan_enqueue(ctxs[r], NULL)) die_gpu("kmpgpu_scan_enqueue");
         if (comm) {
-            /* the shards' own counts are needed again below (offset files): keep a copy before they are summed in place */
-            if (getenv("KMPGPU_OFFSETS_FILE"))
-                for (int r = 0; r < shards; r++) {
-                    job[r].own = (uint64_t *)malloc(sizeof(uint64_t) * pats.n);
-                    if (kmpgpu_counts_read(ctxs[r], job[r].own)) die_gpu("kmpgpu_counts_read");
+            /* the shards' own counts are kept before they are summed in place: the offset files need them again below, and
+             * they are what the host sums should the all-reduce fail (n_patterns x 8 bytes per shard) */
+            for (int r = 0; r < shards; r++) {
+                job[r].own = (uint64_t *)malloc(sizeof(uint64_t) * (pats.n ? pats.n : 1));
+                if (!job[r].own || kmpgpu_counts_read(ctxs[r], job[r].own)) die_gpu("kmpgpu_counts_read");
+            }
+            int bad = kmpgpu_comm_allreduce_counts(comm) != 0;
+            if (!bad) bad = kmpgpu_counts_read(ctxs[0], counts) != 0;                          /* MPI_Reduce root 0 */
+            for (int r = 1; r < shards && !bad; r++) bad = kmpgpu_sync(ctxs[r]) != 0;
+            if (bad) {
+                fprintf(stderr, "[kmpgpu] RCCL all-reduce of the counts: %s -- summing the shards' counts on the host\n", kmpgpu_last_error());
+                reduce_rccl = 0;
+                for (uint32_t i = 0; i < pats.n; i++) {
+                    counts[i] = 0;
+                    for (int r = 0; r < shards; r++) counts[i] += job[r].own[i];            /* mpi_dumping.c:202 MPI_SUM */
                 }
-            if (kmpgpu_comm_allreduce_counts(comm)) die_gpu("kmpgpu_comm_allreduce_counts");
-            if (kmpgpu_counts_read(ctxs[0], counts)) die_gpu("kmpgpu_counts_read");       /* MPI_Reduce root 0 */
-            for (int r = 1; r < shards; r++) if (kmpgpu_sync(ctxs[r])) die_gpu("kmpgpu_sync");
+            }
         } else {
             for (int r = 0; r < shards; r++) {
                 if (kmpgpu_counts_read(ctxs[r], part)) die_gpu("kmpgpu_counts_read");

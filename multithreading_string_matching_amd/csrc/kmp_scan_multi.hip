@@ -174,15 +174,18 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                         hit = eight && m <= 8u;
                         if (eight && m > 8u) {
                             /* rarer: nine bytes or more, the first eight match: the rest straight from the arena (a 0x00 of
-                             * the slot padding, or of the slack behind the last slot, ends the comparison) */
-                            bool ok = true;
+                             * the slot padding ends the comparison).  A window never leaves its payload (serial.c:193,198), so it
+                             * never leaves this wavefront's range, which ends with a slot: that bound is what holds for the LAST
+                             * payload of the index, behind which no packet-start bit follows and the caller's memory may hold
+                             * anything (kmpgpu.h: nothing is required, and nothing is read, behind the last slot). */
+                            bool ok = pos + m <= range;
                             if constexpr (CLEAN) {
                                 /* room only tells 16 / 32 / more there: the exact distance to the next packet start */
                                 const uint64_t a = off0 + pos, b = (a >> 4) + 1ull;
                                 const unsigned long long w0 = bitmap[b >> 6], w1 = bitmap[(b >> 6) + 1ull];
                                 const uint32_t s6 = (uint32_t)(b & 63ull);
                                 const uint64_t bits = s6 ? ((w0 >> s6) | (w1 << (64u - s6))) : w0;
-                                if (bits != 0ull) ok = (uint64_t)m <= ((b + (uint64_t)__builtin_ctzll(bits)) << 4) - a;
+                                if (bits != 0ull) ok = ok && (uint64_t)m <= ((b + (uint64_t)__builtin_ctzll(bits)) << 4) - a;
                             }
                             if (ok) {
                                 const uint8_t *tp = arena + off0 + pos;

@@ -122,7 +122,11 @@ struct kmpgpu_ctx {
     std::vector<hipEvent_t> prof_ev;                  /* pairs */
     uint32_t    prof_cap = 0, prof_n = 0;
     bool        profiling = false;
+
+    struct kmpgpu_comm *comm = nullptr;               /* the communicator this context is a rank of (kmpgpu_comm_*), if any */
 };
+
+static void comm_forget(kmpgpu_comm *k, kmpgpu_ctx *c);
 
 namespace {
 
@@ -472,6 +476,7 @@ int kmpgpu_init(kmpgpu_ctx **out, int device)
 void kmpgpu_destroy(kmpgpu_ctx *c)
 {
     if (!c) return;
+    if (c->comm) comm_forget(c->comm, c);           /* a communicator outliving one of its contexts: it keeps device + stream handle only */
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release_arena(c);
@@ -1204,22 +1209,30 @@ int rccl_load()
 }
 /* RCCL prints its version banner (NCCL_DEBUG=VERSION and above) with printf on the first communicator: stdout belongs
  * to the caller -- the drop-in programs' report (serial.c:163-169) is compared byte for byte -- so file descriptor 1
- * points at stderr while a communicator is being created.  (Another thread of the caller that writes to stdout in
- * exactly that window lands on stderr too.) */
+ * points at stderr while a communicator is being created.  Guards may overlap (one thread per GPU inside
+ * kmpgpu_comm_init_rank, which blocks until every rank has joined): the first one in saves and redirects, the last one
+ * out restores, under a mutex.  (Another thread of the caller that writes to stdout in exactly that window lands on
+ * stderr too.) */
 struct StdoutToStderr {
-    int saved = -1;
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static int &depth() { static int d = 0; return d; }
+    static int &saved() { static int fd = -1; return fd; }
     StdoutToStderr()
     {
+        std::lock_guard<std::mutex> lock(mu());
+        if (depth()++ != 0) return;
         fflush(stdout);
-        saved = dup(1);
-        if (saved >= 0 && dup2(2, 1) < 0) { close(saved); saved = -1; }
+        saved() = dup(1);
+        if (saved() >= 0 && dup2(2, 1) < 0) { close(saved()); saved() = -1; }
     }
     ~StdoutToStderr()
     {
-        if (saved < 0) return;
+        std::lock_guard<std::mutex> lock(mu());
+        if (--depth() != 0 || saved() < 0) return;
         fflush(stdout);
-        (void)dup2(saved, 1);
-        close(saved);
+        (void)dup2(saved(), 1);
+        close(saved());
+        saved() = -1;
     }
 };
 #define RCCL_TRY(expr)                                                                                        \
@@ -1230,10 +1243,23 @@ struct StdoutToStderr {
 }  // namespace
 
 struct kmpgpu_comm {
-    std::vector<kmpgpu_ctx *> ctx;          /* the local ranks' contexts */
+    std::vector<kmpgpu_ctx *> ctx;          /* the local ranks' contexts (nullptr: destroyed before the communicator) */
     std::vector<ncclComm_t>   comm;         /* one communicator handle per local rank */
+    std::vector<int>          device;       /* copies: kmpgpu_comm_destroy must not need the contexts */
     int n_ranks = 0;
 };
+
+static void comm_forget(kmpgpu_comm *k, kmpgpu_ctx *c)
+{
+    for (size_t i = 0; i < k->ctx.size(); i++)
+        if (k->ctx[i] == c) {
+            /* the rank's collectives were enqueued on the context's stream, which is about to go: let them finish */
+            (void)hipSetDevice(c->device);
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            k->ctx[i] = nullptr;
+        }
+    c->comm = nullptr;
+}
 
 extern "C" {
 
@@ -1246,6 +1272,7 @@ int kmpgpu_comm_init(kmpgpu_comm **out, kmpgpu_ctx *const *ctx, int n_ctx)
     std::vector<int> devs;
     for (int i = 0; i < n_ctx; i++) {
         if (!ctx[i]) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: context %d is NULL", i);
+        if (ctx[i]->comm) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: context %d already belongs to a communicator", i);
         if (ctx[i]->n_pat != ctx[0]->n_pat) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init: context %d holds %u patterns, context 0 %u", i, ctx[i]->n_pat, ctx[0]->n_pat);
         for (int d : devs)
             if (d == ctx[i]->device)
@@ -1262,6 +1289,8 @@ int kmpgpu_comm_init(kmpgpu_comm **out, kmpgpu_ctx *const *ctx, int n_ctx)
     ncclResult_t r;
     { StdoutToStderr guard; r = g_rccl.CommInitAll(k->comm.data(), n_ctx, devs.data()); }
     if (r != ncclSuccess) { delete k; return fail(KMPGPU_EHIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r)); }
+    k->device = devs;
+    for (int i = 0; i < n_ctx; i++) ctx[i]->comm = k;
     *out = k;
     return KMPGPU_OK;
 }
@@ -1282,6 +1311,7 @@ int kmpgpu_comm_init_rank(kmpgpu_comm **out, kmpgpu_ctx *ctx, int n_ranks, int r
 {
     if (!out || !ctx || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init_rank: bad arguments");
     *out = nullptr;
+    if (ctx->comm) return fail(KMPGPU_EINVAL, "kmpgpu_comm_init_rank: the context already belongs to a communicator");
     int rc = rccl_load();
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1295,6 +1325,8 @@ int kmpgpu_comm_init_rank(kmpgpu_comm **out, kmpgpu_ctx *ctx, int n_ranks, int r
     ncclResult_t r;
     { StdoutToStderr guard; r = g_rccl.CommInitRank(&k->comm[0], n_ranks, id, rank); }
     if (r != ncclSuccess) { delete k; return fail(KMPGPU_EHIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); }
+    k->device.push_back(ctx->device);
+    ctx->comm = k;
     *out = k;
     return KMPGPU_OK;
 }
@@ -1302,6 +1334,8 @@ int kmpgpu_comm_init_rank(kmpgpu_comm **out, kmpgpu_ctx *ctx, int n_ranks, int r
 int kmpgpu_comm_allreduce_counts(kmpgpu_comm *k)
 {
     if (!k) return fail(KMPGPU_EINVAL, "kmpgpu_comm_allreduce_counts: comm is NULL");
+    for (kmpgpu_ctx *c : k->ctx)
+        if (!c) return fail(KMPGPU_ESTATE, "kmpgpu_comm_allreduce_counts: a context of this communicator has been destroyed");
     const uint32_t n = k->ctx[0]->n_pat;
     for (kmpgpu_ctx *c : k->ctx) {
         if (!c->d_counts) return fail(KMPGPU_ESTATE, "kmpgpu_comm_allreduce_counts: a context has no patterns set");
@@ -1322,9 +1356,13 @@ void kmpgpu_comm_destroy(kmpgpu_comm *k)
 {
     if (!k) return;
     for (size_t i = 0; i < k->comm.size(); i++) {
+        if (k->ctx[i]) {                                    /* (a context destroyed earlier has waited for its stream itself) */
+            (void)hipSetDevice(k->ctx[i]->device);
+            (void)hipStreamSynchronize(k->ctx[i]->stream);
+            k->ctx[i]->comm = nullptr;
+        }
         if (!k->comm[i]) continue;
-        (void)hipSetDevice(k->ctx[i]->device);
-        (void)hipStreamSynchronize(k->ctx[i]->stream);
+        if (i < k->device.size()) (void)hipSetDevice(k->device[i]);
         (void)g_rccl.CommDestroy(k->comm[i]);
     }
     delete k;

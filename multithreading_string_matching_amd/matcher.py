@@ -39,6 +39,7 @@ class GpuMatcher:
         self.device = device
         self.patterns: List[bytes] = []
         self._keep = None          # objects whose device memory the context borrows
+        self._comm = None          # the GpuComm this matcher is a rank of: closed before the context
 
     # -- configuration -------------------------------------------------------------------------
     def set_option(self, key: int, value: int) -> None:
@@ -71,10 +72,12 @@ class GpuMatcher:
                   "kmpgpu_load_arena")
         self._keep = None
 
-    def attach_arena(self, d_arena, d_off, d_len) -> None:
-        """Borrow a device-resident arena: torch uint8 / int64 / int32 CUDA tensors."""
+    def attach_arena(self, d_arena, d_off, d_len, arena_bytes: Optional[int] = None) -> None:
+        """Borrow a device-resident arena: torch uint8 / int64 / int32 CUDA tensors.  arena_bytes: what the library is
+        told the arena holds (default: the whole tensor); the end of the last slot is enough."""
         n = int(d_len.numel())
-        gpu_check(self._g.kmpgpu_attach_arena(self._ctx, d_arena.data_ptr(), int(d_arena.numel()), d_off.data_ptr(),
+        nb = int(d_arena.numel()) if arena_bytes is None else int(arena_bytes)
+        gpu_check(self._g.kmpgpu_attach_arena(self._ctx, d_arena.data_ptr(), nb, d_off.data_ptr(),
                                               d_len.data_ptr(), n), "kmpgpu_attach_arena")
         self._keep = (d_arena, d_off, d_len)
 
@@ -189,6 +192,10 @@ class GpuMatcher:
 
     # -- lifetime ----------------------------------------------------------------------------------
     def close(self) -> None:
+        comm = getattr(self, "_comm", None)
+        if comm is not None:                      # the communicator goes before its contexts (kmpgpu.h)
+            self._comm = None
+            comm.close()
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
             self._g.kmpgpu_destroy(self._ctx)
             self._ctx = C.c_void_p()
@@ -219,6 +226,8 @@ class GpuComm:
         self._matchers = list(matchers)
         arr = (C.c_void_p * len(self._matchers))(*[m._ctx for m in self._matchers])
         gpu_check(self._g.kmpgpu_comm_init(C.byref(self._comm), arr, len(self._matchers)), "kmpgpu_comm_init")
+        for m in self._matchers:
+            m._comm = self
 
     @staticmethod
     def unique_id() -> bytes:
@@ -233,6 +242,7 @@ class GpuComm:
         self._comm = C.c_void_p()
         self._matchers = [matcher]
         gpu_check(self._g.kmpgpu_comm_init_rank(C.byref(self._comm), matcher._ctx, n_ranks, rank, C.c_char_p(unique_id)), "kmpgpu_comm_init_rank")
+        matcher._comm = self
         return self
 
     def allreduce_counts(self) -> None:
@@ -242,6 +252,16 @@ class GpuComm:
         if getattr(self, "_comm", None) is not None and self._comm.value:
             self._g.kmpgpu_comm_destroy(self._comm)
             self._comm = C.c_void_p()
+        for m in getattr(self, "_matchers", []):
+            if getattr(m, "_comm", None) is self:
+                m._comm = None
+        self._matchers = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def __enter__(self):
         return self

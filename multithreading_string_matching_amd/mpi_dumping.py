@@ -72,12 +72,11 @@ def main(argv=None) -> int:
     try:
         stream = torch.cuda.Stream(device=dev)           # the scan and the collective are ordered on one explicit stream
         torch.cuda.set_stream(stream)
-        with GpuMatcher(dev_index) as m:
+        def make_matcher():                              # created INSIDE the flag protocol: the peers wait in its all-reduce
+            m = GpuMatcher(dev_index)
             m.set_stream(stream.cuda_stream)
-            rc = count_and_report(m, patterns, pcap_path, proto, rank, world, dev)
-    except KmpGpuError as e:                             # outside the flag protocol (context creation): nobody waits for this rank yet
-        print(f"mpi_dumping: rank {rank}: {e}", file=sys.stderr)
-        rc = 2
+            return m
+        rc = count_and_report(make_matcher, patterns, pcap_path, proto, rank, world, dev)
     finally:
         if world > 1 and dist.is_initialized():
             dist.destroy_process_group()
@@ -102,7 +101,10 @@ def count_and_report(m, patterns, pcap_path, proto, rank, world, dev, out=None) 
 
     out = sys.stdout if out is None else out
     flag = torch.zeros(1, dtype=torch.int64, device=dev)
+    own = None
     try:
+        if not hasattr(m, "scan_enqueue"):               # a factory: the context is created here, under the flag
+            m = own = m()
         if patterns:
             m.set_patterns(patterns)
         m.load_pcap_frames(pcap_path, proto, rank, world)       # this rank's frames: extraction on the GPU
@@ -114,27 +116,41 @@ def count_and_report(m, patterns, pcap_path, proto, rank, world, dev, out=None) 
     except KmpGpuError as e:
         print(f"mpi_dumping: rank {rank}: {e}", file=sys.stderr)
         flag += GPU_ERROR
-    kd.reduce_counts(flag)
-    failed = int(flag.item())
-    if failed >= GPU_ERROR:
-        return 2
-    if failed:
+    try:
+        kd.reduce_counts(flag)
+        failed = int(flag.item())
+        if failed >= GPU_ERROR:
+            return 2
+        if failed:
+            return 0
+        kd.barrier()                                     # mpi_dumping.c:167-168
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # the counters and, behind them, one more word: a rank whose pass could not be enqueued raises it, and it travels
+        # with the counters through the SAME all-reduce -- a failure after the flag leaves no rank waiting either
+        n = len(patterns)
+        counts = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        if patterns:
+            try:
+                m.scan_enqueue(counts)                   # mpi_dumping.c:198-200 (extraction already done on the device)
+            except KmpGpuError as e:
+                print(f"mpi_dumping: rank {rank}: {e}", file=sys.stderr)
+                counts[n] = 1
+        kd.reduce_counts(counts)                         # mpi_dumping.c:202 MPI_SUM
+        host_counts = counts.cpu().tolist()
+        if host_counts[n]:
+            return 2
+        total = host_counts[:n]
+        elapsed = kd.max_over_ranks(time.perf_counter() - t0, device=dev)      # mpi_dumping.c:206 MPI_MAX
+        if rank == 0:                                    # mpi_dumping.c:208-214
+            out.write(host.format_report(patterns, total))
+            out.write(f"Elapsed time = {elapsed:f} seconds\n")
+            out.flush()
         return 0
-    kd.barrier()                                         # mpi_dumping.c:167-168
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    counts = torch.zeros(max(len(patterns), 1), dtype=torch.int64, device=dev)
-    if patterns:
-        m.scan_enqueue(counts)                           # mpi_dumping.c:198-200 (extraction already done on the device)
-    kd.reduce_counts(counts)                             # mpi_dumping.c:202 MPI_SUM
-    total = counts.cpu().tolist()[:len(patterns)]
-    elapsed = kd.max_over_ranks(time.perf_counter() - t0, device=dev)      # mpi_dumping.c:206 MPI_MAX
-    if rank == 0:                                        # mpi_dumping.c:208-214
-        out.write(host.format_report(patterns, total))
-        out.write(f"Elapsed time = {elapsed:f} seconds\n")
-        out.flush()
-    return 0
+    finally:
+        if own is not None:
+            own.close()
 
 
 if __name__ == "__main__":

@@ -146,3 +146,21 @@ def test_mpi_dumping_rank_protocol_never_leaves_a_rank_waiting(fail_on, want_rc)
         assert "cc:" not in res[0][2] and res[1][2] == ""
     else:
         assert res[0][2] == "" and res[1][2] == ""
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how a driver may call the scale run): the parent starts the two
+    ranks itself under torch.distributed.run and hands their exit code on.  In this container there is no GPU, so each rank
+    stops at bench.py's own 'needs an MI355X' check -- which shows that two ranks ran, with RANK/WORLD_SIZE set, and that
+    their failure is not swallowed; the parent itself never gets as far as a GPU call."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU form of this test; on a GPU box test_gpu_parity.py rehearses two ranks for real")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    assert r.stdout.strip() == ""

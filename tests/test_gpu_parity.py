@@ -17,6 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
+# torch first: its wheel carries its own ROCm runtime libraries, and a process in which /opt/rocm's libamdhip64 (what libkmpgpu.so
+# links) is loaded BEFORE torch's ends up with torch seeing "No HIP GPUs" (seen when this file was run on its own; in the whole
+# suite tests/test_dist.py imports torch earlier).  The C-ABI library itself does not care which of the two it gets.
+import torch  # noqa: E402,F401
+
 import multithreading_string_matching_amd as K  # noqa: E402
 from multithreading_string_matching_amd import _lib  # noqa: E402
 from multithreading_string_matching_amd.matcher import (  # noqa: E402
@@ -511,6 +516,86 @@ def test_dirty_slot_padding(gm, oracle, uniform):
                 assert arena[o:o + len(p)].tobytes() == p and int(r["offset"]) + len(p) <= lens[int(r["packet"])]
     finally:
         gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
+
+
+def _all_kernel_counts(gm, pats, attach):
+    """Counts of `pats` together (fused pass) and one by one on every kernel family, for an arena `attach()` brings in."""
+    out = {}
+    try:
+        gm.set_option(OPT_MODE, MODE_FILTER)
+        gm.set_patterns(pats)
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 1)
+        attach()
+        out["fused"] = gm.scan()[0].tolist()
+        gm.set_option(OPT_FUSED, 0)
+        for name, mode, kernel in (("auto", MODE_FILTER, KERNEL_AUTO), ("flat", MODE_FILTER, KERNEL_FLAT), ("packed", MODE_FILTER, KERNEL_PACKED),
+                                   ("general", MODE_FILTER, KERNEL_GENERAL), ("automaton", MODE_AUTOMATON, KERNEL_GENERAL)):
+            got = []
+            for p in pats:
+                gm.set_option(OPT_MODE, mode); gm.set_option(OPT_KERNEL, kernel)
+                gm.set_patterns([p])
+                attach()
+                got.append(int(gm.scan()[0][0]))
+            out[name] = got
+    finally:
+        gm.set_option(OPT_MODE, MODE_FILTER); gm.set_option(OPT_KERNEL, KERNEL_AUTO); gm.set_option(OPT_FUSED, 2)
+    return out
+
+
+@pytest.mark.parametrize("L", [64, 1504, 48])
+def test_nothing_behind_the_last_slot_is_read_or_counted(gm, oracle, L):
+    """serial.c:193,198: a window never leaves its payload -- also not the LAST payload of the index, whose slot is
+    followed by whatever the caller keeps there (kmpgpu.h: nothing is required behind the last slot).  A device buffer
+    of one letter is attached through prefix views of its index, so that the text simply goes on behind the last
+    attached payload, which fills its slot (L % 16 == 0): a matcher that bounds the window by 'the next packet start'
+    alone counts the windows that straddle the view's end.  arena_bytes once generous, once exactly the last slot's end."""
+    import torch
+    n = 40
+    pats = [b"a" * 9, b"a" * 40, b"a" * 99, b"ab", b"a" * 20, b"a" * 19 + b"b"]
+    host = np.full(n * L + 256, ord("a"), dtype=np.uint8)
+    off = (np.arange(n, dtype=np.uint64) * L)
+    ln = np.full(n, L, dtype=np.uint32)
+    d_arena = torch.from_numpy(host).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(ln.astype(np.int32)).cuda()
+    torch.cuda.synchronize()
+    gm.set_stream(None)
+    for keep in (n - 1, 1, 17):
+        want = oracle.count(host, off[:keep], ln[:keep], pats)[0].tolist()
+        assert want[0] == keep * (L - 8)
+        for nbytes in (None, keep * L):
+            got = _all_kernel_counts(gm, pats, lambda: gm.attach_arena(d_arena, d_off[:keep], d_len[:keep], arena_bytes=nbytes))
+            assert all(v == want for v in got.values()), (L, keep, nbytes, want, {k: v for k, v in got.items() if v != want})
+    # a pattern whose first bytes end the last payload and whose rest stands behind the view
+    tail = b"abcdefghijklmnopqrst"
+    for cut in (8, 12, 16, 19):
+        h2 = host.copy()
+        keep = 23
+        end = keep * L
+        h2[end - cut:end - cut + len(tail)] = np.frombuffer(tail, dtype=np.uint8)       # straddles the end of payload keep-1
+        h2[5 * L + 3:5 * L + 3 + len(tail)] = np.frombuffer(tail, dtype=np.uint8)        # and once inside payload 5
+        d2 = torch.from_numpy(h2).cuda()
+        torch.cuda.synchronize()
+        p2 = [tail, tail[:9], b"ab", tail[:cut]]
+        want = oracle.count(h2, off[:keep], ln[:keep], p2)[0].tolist()
+        assert want[0] == 1
+        for nbytes in (None, end):
+            got = _all_kernel_counts(gm, p2, lambda: gm.attach_arena(d2, d_off[:keep], d_len[:keep], arena_bytes=nbytes))
+            assert all(v == want for v in got.values()), (L, cut, nbytes, want, got)
+        del d2
+    # the library's own copy: a tight host arena (no slack behind the last slot), and a shorter batch loaded into the
+    # device buffers of a longer one (bin/openmp_task reuses them): the earlier batch's text stands behind the new end
+    gm.set_option(OPT_FUSED, 1)
+    try:
+        gm.set_patterns(pats)
+        gm.load_arena(host[: n * L], off, ln)
+        assert gm.scan()[0].tolist() == oracle.count(host, off, ln, pats)[0].tolist()
+        for keep in (n - 3, 2):
+            gm.load_arena(host[: keep * L], off[:keep], ln[:keep])
+            assert gm.scan()[0].tolist() == oracle.count(host, off[:keep], ln[:keep], pats)[0].tolist(), keep
+    finally:
+        gm.set_option(OPT_FUSED, 2)
+    del d_arena, d_off, d_len
 
 
 def test_layout_contract_is_checked(gm):
