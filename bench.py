@@ -222,6 +222,18 @@ def extra_configs(m, dev, passes, headline, sample97):
             raise SystemExit(f"extra {name}: count {int(got[0])} != planted {want}")
         timed(name, f"{nn} payloads of {lo}..{hi} B, one 16-byte pattern in ~10 % of packets (a candidate in most 1 KiB chunks)", pb,
               f"count == planted ({want})")
+        if lo == hi:
+            # the same 64-byte payloads under the 97 patterns: sixteen packet starts per 1 KiB chunk in the fused pass
+            m.set_option(OPT_FUSED, 0)
+            m.set_patterns(pats97)
+            m.attach_arena(d_a, d_o, d_l)
+            per_pattern, _ = m.scan()
+            m.set_option(OPT_FUSED, 2)
+            m.attach_arena(d_a, d_o, d_l)
+            fused, _ = m.scan()
+            if fused.tolist() != per_pattern.tolist():
+                raise SystemExit("extra 64 B x 97: fused counts differ from the per-pattern passes")
+            timed("small_64B_x_97_fused", f"the same {nn} payloads of {lo} B, strings.txt (97 patterns), fused pass", pb, "fused == 97 single-pattern passes")
         del d_a, d_o, d_l
         torch.cuda.empty_cache()
 

@@ -135,6 +135,13 @@ kmp_batch_reader *kmp_batch_open(const char *path, int proto, char errbuf[KMP_PC
  * (slack included), *frames += records read. */
 int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, uint64_t *off, uint32_t *len,
                        uint64_t cap_pkts, uint64_t *used_bytes, uint64_t *frames);
+/* The same producer with the extraction left to the GPU (kmpgpu_load_frames): the next records of the capture whose bytes
+ * span at most max_span_bytes of the file (at least one record, at most cap_frames).  Only the record headers are read;
+ * frame_off[f] / frame_caplen[f] locate the frames inside the buffer kmp_batch_file() returns (the mapped capture itself:
+ * nothing is copied).  Returns the number of frames (0 = end of capture).  A reader serves either kind of batch, not both. */
+int64_t kmp_batch_next_frames(kmp_batch_reader *r, uint64_t max_span_bytes, uint64_t *frame_off, uint32_t *frame_caplen,
+                              uint64_t cap_frames);
+const uint8_t *kmp_batch_file(const kmp_batch_reader *r, uint64_t *nbytes);
 void kmp_batch_close(kmp_batch_reader *r);
 
 /* Synthetic fill on the host (same bytes as the device generator, kmp_synth.h). */

@@ -104,6 +104,8 @@ HOST_API = {
     "kmp_frames_free": (None, [C.POINTER(Frames)]),
     "kmp_batch_open": (C.c_void_p, [C.c_char_p, C.c_int, C.c_char_p]),
     "kmp_batch_next": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p]),
+    "kmp_batch_next_frames": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kmp_batch_file": (C.c_void_p, [C.c_void_p, u64p]),
     "kmp_batch_close": (None, [C.c_void_p]),
     "kmp_synth_fill_host": (None, [u8p, u64p, u32p, C.c_uint64, C.c_uint64, C.POINTER(SynthParams), C.c_int]),
     "kmp_synth_count_planted": (C.c_uint64, [u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(SynthParams)]),

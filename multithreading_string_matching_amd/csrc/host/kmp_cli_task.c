@@ -11,6 +11,10 @@
  * overlaps the scan of the previous one; the contexts accumulate counts over their batches
  * (KMPGPU_OPT_ACCUMULATE) and the totals are summed at the end (openmp_task.c:172-175).
  *
+ * KMPGPU_DEVICE_EXTRACT=1 (SURVEY 8(f) N2 x N3): the producer only walks the record headers of the mapped capture
+ * (kmp_batch_next_frames) and the consumers upload the RAW frames of a batch straight from the mapping and extract the
+ * payloads on the GPU (kmpgpu_load_frames, packet_dumping.h:87-188 on the device): no payload is copied on the host.
+ *
  * stdout is byte-compatible with the reference (openmp_task.c:190-196).  No CPU fallback: exit code 2
  * without a gfx950 device.
  */
@@ -26,9 +30,9 @@
 #define SLOTS_PER_SHARD 3
 
 typedef struct slot {
-    uint8_t  *arena;
-    uint64_t *off;
-    uint32_t *len;
+    uint8_t  *arena;                 /* payload batches: pinned arena; frame batches: unused (the frames stay in the mapped capture) */
+    uint64_t *off;                   /* payload offsets in arena / frame offsets in the capture */
+    uint32_t *len;                   /* payload lengths / captured lengths of the frames       */
     uint64_t  used, n;
     int       state;                 /* 0 free, 1 filled */
 } slot;
@@ -44,6 +48,11 @@ typedef struct shared {
     const uint8_t **pp;
     int             ndev;
     int             failed;
+    int             ready;           /* consumers whose contexts are up */
+    /* KMPGPU_DEVICE_EXTRACT=1: batches of raw frames of the mapped capture */
+    int             frames_mode, tcp;
+    const uint8_t  *file;
+    uint64_t        file_bytes;
 } shared;
 
 typedef struct consumer {
@@ -76,7 +85,12 @@ static void *consume(void *arg)
         if (kmpgpu_init(&ctx[i], me->id % sh->ndev)) die_gpu("kmpgpu_init");
         if (kmpgpu_set_patterns(ctx[i], sh->pp, sh->pats->len, sh->pats->n)) die_gpu("kmpgpu_set_patterns");
         if (kmpgpu_set_option(ctx[i], KMPGPU_OPT_ACCUMULATE, 1) || kmpgpu_counts_reset(ctx[i])) die_gpu("kmpgpu_set_option");
+        if (kmpgpu_sync(ctx[i])) die_gpu("kmpgpu_sync");
     }
+    pthread_mutex_lock(&sh->mu);                               /* the contexts are up: the clock may start (main waits for every consumer) */
+    sh->ready++;
+    pthread_cond_broadcast(&sh->cv);
+    pthread_mutex_unlock(&sh->mu);
     int turn = 0;
     for (;;) {
         pthread_mutex_lock(&sh->mu);
@@ -89,8 +103,16 @@ static void *consume(void *arg)
         kmpgpu_ctx *c = ctx[turn];
         turn ^= 1;
         /* waits for this context's previous scan, uploads (the other context's scan keeps running) */
-        if (kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n)) die_gpu("kmpgpu_load_arena");
-        me->batches++; me->payloads += s->n;
+        if (sh->frames_mode) {
+            uint64_t np = 0, pb = 0;
+            if (kmpgpu_load_frames(c, sh->file, sh->file_bytes, s->off, s->len, s->n, sh->tcp, &np)) die_gpu("kmpgpu_load_frames");
+            kmpgpu_arena_info(c, NULL, &pb);
+            me->payloads += np; me->bytes += np ? pb : 0;
+        } else {
+            if (kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n)) die_gpu("kmpgpu_load_arena");
+            me->payloads += s->n;
+        }
+        me->batches++;
         pthread_mutex_lock(&sh->mu);
         s->state = 0;                                        /* the pinned buffer may be refilled */
         pthread_cond_broadcast(&sh->cv);
@@ -140,8 +162,11 @@ int main(int argc, char *argv[])
 
     uint64_t batch_bytes = 64ull << 20;
     const char *env = getenv("KMPGPU_BATCH_BYTES");
-    if (env && atoll(env) >= (1 << 20)) batch_bytes = (uint64_t)atoll(env);
-    const uint64_t cap_pkts = batch_bytes / 64;
+    if (env && atoll(env) >= (1 << 16)) batch_bytes = (uint64_t)atoll(env);                 /* 64 KiB and up: a frame (<= 64 KiB captured) always fits */
+    const char *dx = getenv("KMPGPU_DEVICE_EXTRACT");
+    const int frames_mode = dx && dx[0] == '1';
+    /* a frame record takes 16 bytes of header and up; a payload slot 16 bytes and up, 64 on average or more in practice */
+    const uint64_t cap_pkts = frames_mode ? batch_bytes / 32 : batch_bytes / 64;
 
     shared sh;
     memset(&sh, 0, sizeof sh);
@@ -150,16 +175,19 @@ int main(int argc, char *argv[])
     sh.n_slots = SLOTS_PER_SHARD * shards;
     sh.slots = (slot *)calloc((size_t)sh.n_slots, sizeof(slot));
     sh.pats = &pats; sh.ndev = ndev;
+    sh.frames_mode = frames_mode; sh.tcp = proto == KMP_PROTO_TCP;
+    sh.file = kmp_batch_file(rd, &sh.file_bytes);
     sh.pp = (const uint8_t **)malloc(sizeof(uint8_t *) * (pats.n ? pats.n : 1));
     for (uint32_t i = 0; i < pats.n; i++) sh.pp[i] = pats.blob + pats.off[i];
     for (int i = 0; i < sh.n_slots; i++) {
-        sh.slots[i].arena = (uint8_t *)kmpgpu_host_alloc((size_t)batch_bytes);
+        sh.slots[i].arena = frames_mode ? NULL : (uint8_t *)kmpgpu_host_alloc((size_t)batch_bytes);
         sh.slots[i].off = (uint64_t *)kmpgpu_host_alloc((size_t)cap_pkts * sizeof(uint64_t));
         sh.slots[i].len = (uint32_t *)kmpgpu_host_alloc((size_t)cap_pkts * sizeof(uint32_t));
-        if (!sh.slots[i].arena || !sh.slots[i].off || !sh.slots[i].len) die_gpu("kmpgpu_host_alloc");
+        if ((!frames_mode && !sh.slots[i].arena) || !sh.slots[i].off || !sh.slots[i].len) die_gpu("kmpgpu_host_alloc");
     }
 
-    const double t_start = now_s();                                                                 /* openmp_task.c:124 */
+    /* The consumers and their GPU contexts (streams, pattern tables) are set up before the clock starts, like the pinned
+     * buffers above and like everything openmp_task.c does before :124 (pattern load, pcap_open_offline, allocations). */
     consumer *cons = (consumer *)calloc((size_t)shards, sizeof(consumer));
     pthread_t *th = (pthread_t *)calloc((size_t)shards, sizeof(pthread_t));
     if (pats.n) {
@@ -167,19 +195,31 @@ int main(int argc, char *argv[])
             cons[r].sh = &sh; cons[r].id = r;
             pthread_create(&th[r], NULL, consume, &cons[r]);
         }
+        pthread_mutex_lock(&sh.mu);
+        while (sh.ready < shards) pthread_cond_wait(&sh.cv, &sh.mu);
+        pthread_mutex_unlock(&sh.mu);
     }
+    const double t_start = now_s();                                                                 /* openmp_task.c:124 */
     uint64_t frames = 0, payloads = 0, bytes = 0, batches = 0;
     for (;;) {                                                                                      /* openmp_task.c:130-155: the producer */
         slot *s = &sh.slots[sh.next_fill % (uint64_t)sh.n_slots];
         pthread_mutex_lock(&sh.mu);
         while (s->state != 0) pthread_cond_wait(&sh.cv, &sh.mu);
         pthread_mutex_unlock(&sh.mu);
-        const int64_t n = kmp_batch_next(rd, s->arena, batch_bytes, s->off, s->len, cap_pkts, &s->used, &frames);
+        int64_t n;
+        if (frames_mode) {
+            n = kmp_batch_next_frames(rd, batch_bytes, s->off, s->len, cap_pkts);                   /* record headers only */
+            if (n > 0) frames += (uint64_t)n;
+        } else
+            n = kmp_batch_next(rd, s->arena, batch_bytes, s->off, s->len, cap_pkts, &s->used, &frames);
         if (n < 0) { fprintf(stderr, "error reading pcap file: a payload exceeds KMPGPU_BATCH_BYTES\n"); exit(1); }
         if (n == 0) break;
         s->n = (uint64_t)n;
-        payloads += s->n; batches++;
-        for (uint64_t k = 0; k < s->n; k++) bytes += s->len[k];
+        batches++;
+        if (!frames_mode) {
+            payloads += s->n;
+            for (uint64_t k = 0; k < s->n; k++) bytes += s->len[k];
+        }
         if (!pats.n) continue;
         pthread_mutex_lock(&sh.mu);
         s->state = 1;
@@ -199,35 +239,41 @@ int main(int argc, char *argv[])
         for (int r = 0; r < shards; r++) {
             pthread_join(th[r], NULL);
             tot[r] = cons[r].total;
+            if (frames_mode) { payloads += cons[r].payloads; bytes += cons[r].bytes; }              /* what the GPUs extracted */
         }
         /* The sum over the shards (mpi_dumping.c:202): one shard per device -> RCCL all-reduce of the device counters and
          * one download; shards that share a device -> host sum.  KMPGPU_RCCL=0 / 1 as in bin/openmp_data. */
         const char *rccl_env = getenv("KMPGPU_RCCL");
         kmpgpu_comm *comm = NULL;
+        /* every shard's own totals first: what the host sums when there is no communicator or the all-reduce fails */
+        uint64_t *part = (uint64_t *)calloc((size_t)shards * pats.n, sizeof(uint64_t));
+        for (int r = 0; r < shards; r++)
+            if (kmpgpu_counts_read(tot[r], part + (size_t)r * pats.n)) die_gpu("kmpgpu_counts_read");
         if (shards <= ndev && (shards > 1 || (rccl_env && rccl_env[0] == '1')) && !(rccl_env && rccl_env[0] == '0')) {
-            if (kmpgpu_comm_init(&comm, tot, shards)) die_gpu("kmpgpu_comm_init");
-            if (kmpgpu_comm_allreduce_counts(comm)) die_gpu("kmpgpu_comm_allreduce_counts");
-            if (kmpgpu_counts_read(tot[0], counts)) die_gpu("kmpgpu_counts_read");
-            for (int r = 1; r < shards; r++) if (kmpgpu_sync(tot[r])) die_gpu("kmpgpu_sync");
-            kmpgpu_comm_destroy(comm);
-            reduce_rccl = 1;
-        } else {
-            uint64_t *part = (uint64_t *)calloc(pats.n, sizeof(uint64_t));
-            for (int r = 0; r < shards; r++) {
-                if (kmpgpu_counts_read(tot[r], part)) die_gpu("kmpgpu_counts_read");
-                for (uint32_t i = 0; i < pats.n; i++) counts[i] += part[i];
-            }
-            free(part);
+            int bad = kmpgpu_comm_init(&comm, tot, shards) != 0;
+            if (!bad) bad = kmpgpu_comm_allreduce_counts(comm) != 0;
+            if (!bad) bad = kmpgpu_counts_read(tot[0], counts) != 0;
+            for (int r = 1; r < shards && !bad; r++) bad = kmpgpu_sync(tot[r]) != 0;
+            if (bad) fprintf(stderr, "[kmpgpu] RCCL count reduce: %s -- summing the shards' counts on the host\n", kmpgpu_last_error());
+            else reduce_rccl = 1;
+            if (comm) kmpgpu_comm_destroy(comm);
         }
+        if (!reduce_rccl) {
+            for (uint32_t i = 0; i < pats.n; i++) {
+                counts[i] = 0;
+                for (int r = 0; r < shards; r++) counts[i] += part[(size_t)r * pats.n + i];          /* mpi_dumping.c:202 MPI_SUM */
+            }
+        }
+        free(part);
         for (int r = 0; r < shards; r++) kmpgpu_destroy(tot[r]);
         free(tot);
     }
     const double t_finish = now_s();                                                                /* openmp_task.c:188 */
 
     kmp_report(stdout, &pats, counts, t_finish - t_start);                                         /* openmp_task.c:190-196 */
-    fprintf(stderr, "[kmpgpu] streamed %llu frames, %llu payloads, %llu payload bytes in %llu batch(es) of <= %llu MiB over %d shard(s), count reduce: %s: %.3f s, %.2f GB/s end to end\n",
+    fprintf(stderr, "[kmpgpu] streamed %llu frames, %llu payloads, %llu payload bytes in %llu batch(es) of <= %llu MiB (%s) over %d shard(s), count reduce: %s: %.3f s, %.2f GB/s end to end\n",
             (unsigned long long)frames, (unsigned long long)payloads, (unsigned long long)bytes, (unsigned long long)batches,
-            (unsigned long long)(batch_bytes >> 20), shards, reduce_rccl ? "RCCL all-reduce" : (shards > 1 ? "host sum" : "none"), t_finish - t_start,
+            (unsigned long long)(batch_bytes >> 20), frames_mode ? "raw frames, extraction on the GPU" : "payloads extracted on the host", shards, reduce_rccl ? "RCCL all-reduce" : (shards > 1 ? "host sum" : "none"), t_finish - t_start,
             (double)bytes / (t_finish - t_start) / 1e9);
 
     kmp_batch_close(rd);

@@ -686,6 +686,31 @@ int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, 
     return (int64_t)n;
 }
 
+/* openmp_task.c:130-137 with the extraction left to the device: record headers only. */
+int64_t kmp_batch_next_frames(kmp_batch_reader *r, uint64_t max_span_bytes, uint64_t *frame_off, uint32_t *frame_caplen,
+                              uint64_t cap_frames)
+{
+    if (!r || !frame_off || !frame_caplen || cap_frames == 0) return KMPHOST_EINVAL;
+    uint64_t n = 0, first = 0;
+    while (!r->eof && n < cap_frames) {
+        const uint64_t before = r->walk.pos;
+        uint32_t cl, ln;
+        const uint8_t *data;
+        if (walk_next(&r->walk, &cl, &ln, &data) < 0) { r->eof = 1; break; }                  /* openmp_task.c:135 */
+        const uint64_t o = (uint64_t)(data - r->view.base);
+        if (n == 0) first = o;
+        else if (o + cl - first > max_span_bytes) { r->walk.pos = before; break; }           /* this record opens the next batch */
+        frame_off[n] = o; frame_caplen[n] = cl; n++;
+    }
+    return (int64_t)n;
+}
+
+const uint8_t *kmp_batch_file(const kmp_batch_reader *r, uint64_t *nbytes)
+{
+    if (nbytes) *nbytes = r ? r->view.size : 0;
+    return r ? r->view.base : NULL;
+}
+
 void kmp_batch_close(kmp_batch_reader *r)
 {
     if (!r) return;

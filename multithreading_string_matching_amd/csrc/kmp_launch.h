@@ -16,6 +16,7 @@ struct kmp_scan_args {
     const uint32_t        *pat_ids;      /* pattern index handled by blockIdx.y              */
     uint32_t               n_ids;        /* gridDim.y                                        */
     unsigned long long    *partials;     /* [n_ids][blocks_x]                                */
+    unsigned long long    *zero_counts;  /* flat / packed kernels: counts[] to put to 0 for the patterns of this launch (sliced reduce without accumulation), or NULL */
     uint32_t               blocks_x;
     int                    depth;        /* chunk loads in flight per wavefront              */
     int                    mode;         /* 0 filter + confirm, 1 automaton only             */
@@ -43,8 +44,10 @@ hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uin
                            void *plan, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr,
-                             int accumulate = 0, unsigned long long *scratch = nullptr, uint32_t *tickets = nullptr);
-#define KMP_REDUCE_SCRATCH_WORDS 64u      /* per pattern of a launch: kmp_reduce_kernel's slice sums (KMP_REDUCE_MAX_SLICES) */
+                             int accumulate = 0, bool counts_zeroed = false);
+#define KMP_REDUCE_SLICE 4096u            /* partials one block of kmp_reduce_kernel adds up */
+/* more than 16384 partials per pattern are summed by several blocks that ADD to counts[]: the scan kernel zeroes it first (zero_counts) */
+static inline bool kmp_reduce_is_sliced(uint32_t blocks_x) { return blocks_x > 16384u; }
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st);
 size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves);

@@ -173,22 +173,22 @@ kmp_gather_kernel(const uint8_t *__restrict__ file, const uint64_t *__restrict__
     }
 }
 
-/* counts[pat_ids[y]] = sum of that pattern's block partials.  The persistent grids leave a thousand partials or two per
- * pattern: one 256-thread block each.  The flat kernel's grid is one block per 16 packets -- 62 500 partials per million
- * packets, 500 000 for an 8 M-packet shard -- which one block would take 60 us to add up: the row is cut into gridDim.y
- * slices, every slice block leaves its sum in `scratch` and takes a ticket, and the block that draws the last ticket adds the
- * slice sums up, writes the count and puts the ticket counter back to 0 for the next pass. */
+/* counts[pat_ids[x]] = sum of that pattern's block partials.  The persistent grids leave a thousand partials or two per pattern: one
+ * 256-thread block each.  The flat kernel's grid is one block per 16 packets -- 62 500 partials per million packets, 500 000 for an
+ * 8 M-packet shard --, which one block would take 60 us to add up: the row is cut into gridDim.y slices of KMP_REDUCE_SLICE partials
+ * and every slice block ADDS its sum to the counter with an atomic add that returns nothing (integer sums: the result does not
+ * depend on the order).  The counter was put to 0 by the scan kernel itself, one kernel boundary earlier, unless the pass
+ * accumulates.  (Round 2 left the slice sums in a scratch row and let the block that drew the last ticket add them up: one
+ * returning atomic and a dependent read more, 6.2 us per launch.) */
 #define KMP_REDUCE_THREADS 1024u
-#define KMP_REDUCE_MAX_SLICES 64u
 __global__ void __launch_bounds__(KMP_REDUCE_THREADS)
 kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t blocks_x,
                   const uint32_t *__restrict__ pat_ids, const uint32_t *__restrict__ rows,
-                  unsigned long long *__restrict__ counts, int accumulate, unsigned long long *__restrict__ scratch,
-                  uint32_t *__restrict__ tickets)
+                  unsigned long long *__restrict__ counts, int accumulate)
 {
     __shared__ unsigned long long s[KMP_REDUCE_THREADS / KMP_WAVE];
     unsigned long long t = 0ull;
-    /* rows == nullptr: row y of partials belongs to pat_ids[y]; else row rows[y] (fused pass: duplicates share a row) */
+    /* rows == nullptr: row x of partials belongs to pat_ids[x]; else row rows[x] (fused pass: duplicates share a row) */
     const unsigned long long *row = partials + (uint64_t)(rows ? rows[blockIdx.x] : blockIdx.x) * blocks_x;
     const uint32_t slices = gridDim.y;
     const uint32_t per = (blocks_x + slices - 1u) / slices;
@@ -209,23 +209,9 @@ kmp_reduce_kernel(const unsigned long long *__restrict__ partials, uint32_t bloc
     if (threadIdx.x == 0u) {
         unsigned long long r = 0ull;
         for (uint32_t w = 0; w < blockDim.x / KMP_WAVE; ++w) r += s[w];
-        bool last = true;
-        if (slices > 1u) {
-            __hip_atomic_store(&scratch[(uint64_t)blockIdx.x * KMP_REDUCE_MAX_SLICES + blockIdx.y], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t ticket = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            last = ticket == slices - 1u;
-            if (last) {
-                r = 0ull;
-                for (uint32_t k = 0; k < slices; ++k)
-                    r += __hip_atomic_load(&scratch[(uint64_t)blockIdx.x * KMP_REDUCE_MAX_SLICES + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if (last) {
-            /* accumulate: counts keep adding up over the batches of a streamed capture (openmp_task.c:172-175) */
-            unsigned long long *dst = counts + pat_ids[blockIdx.x];
-            *dst = accumulate ? *dst + r : r;
-        }
+        unsigned long long *dst = counts + pat_ids[blockIdx.x];
+        if (slices > 1u) { if (r) __hip_atomic_fetch_add(dst, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else *dst = accumulate ? *dst + r : r;       /* accumulate: counts keep adding up over the batches of a streamed capture (openmp_task.c:172-175) */
     }
 }
 
@@ -378,14 +364,15 @@ hipError_t kmp_launch_repack_phase2(const uint8_t *old_arena, const uint64_t *ol
 
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows, int accumulate,
-                             unsigned long long *scratch, uint32_t *tickets)
+                             bool counts_zeroed)
 {
     if (n_ids == 0) return hipSuccess;
-    /* one slice per 4096 partials when the caller has the scratch for it (n_ids x KMP_REDUCE_MAX_SLICES words, n_ids tickets at 0) */
+    /* one slice per KMP_REDUCE_SLICE partials where the caller has seen to the counter's starting value (it accumulates, or the scan
+     * kernel has put it to 0: kmp_scan_args::zero_counts) */
     uint32_t slices = 1u;
-    if (scratch && tickets && blocks_x > 16384u) slices = std::min<uint32_t>(KMP_REDUCE_MAX_SLICES, (blocks_x + 4095u) / 4096u);
+    if (kmp_reduce_is_sliced(blocks_x) && (accumulate || counts_zeroed)) slices = std::min<uint32_t>(256u, (blocks_x + KMP_REDUCE_SLICE - 1u) / KMP_REDUCE_SLICE);
     hipLaunchKernelGGL(kmp_reduce_kernel, dim3(n_ids, slices), dim3(blocks_x > 8192u ? KMP_REDUCE_THREADS : KMP_BLOCK_THREADS), 0, st, partials, blocks_x,
-                       pat_ids, rows, counts, accumulate, scratch, tickets);
+                       pat_ids, rows, counts, accumulate);
     return hipGetLastError();
 }
 

@@ -363,7 +363,19 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                         constexpr bool ONES_BY_MASK = ONES && CLEAN && !EMIT;
                         const bool seg = dead_in || (zl & ~last_lanes) != 0ull;
                         if (seg) nl = nul_limit(15, w, zl, st, dead_in, lane);
-                        else if (ballot64(zm != 0u && ((ONES && !ONES_BY_MASK) || hm != 0u)) != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);
+                        else if constexpr (ONES && !ONES_BY_MASK) {
+                            if (zl != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);           /* the 1-byte patterns below count against nl */
+                        } else if (ballot64(zm != 0u && hm != 0u) != 0ull) {
+                            /* A 0x00 in the last lane of its packet (slot padding, a trailer) bars that lane's own later start offsets and
+                             * nothing else: zb has bit 4q + b for byte b of dword q (the has-zero masks hold 0x80 per zero byte; v_dot4 packs
+                             * them), and the hits that stay are those below its lowest bit -- all of them in a lane without a 0x00.  Eleven
+                             * instructions where the segmented form (nul_limit) takes ~40; with payloads of a few hundred bytes it ran
+                             * on four chunks in ten. */
+                            const uint32_t zlo = __builtin_amdgcn_udot4(z[1] >> 7, 0x80402010u, __builtin_amdgcn_udot4(z[0] >> 7, 0x08040201u, 0u, false), false);
+                            const uint32_t zhi = __builtin_amdgcn_udot4(z[3] >> 7, 0x80402010u, __builtin_amdgcn_udot4(z[2] >> 7, 0x08040201u, 0u, false), false);
+                            const uint32_t zb = zlo | (zhi << 8);
+                            hm &= (zb - 1u) & ~zb;
+                        }
                         /* (the payload's end is not applied to the hit mask: level 2 checks every hit's room, m <= rem - offset) */
                         if (ONES_BY_MASK && !seg) {
                             /* The 1-byte patterns, common case: no 0x00 but in the last lane of a packet, padding all 0x00.  A text byte

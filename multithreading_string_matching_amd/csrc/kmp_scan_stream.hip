@@ -61,7 +61,7 @@ template <int DEPTH, bool NT, bool EMIT = false>
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_t stride, uint32_t L,
                      uint32_t pkts_per_wave, const kmp_pattern_dev *__restrict__ patterns,
-                     const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em)
+                     const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, unsigned long long *__restrict__ zero_counts, Emitter em)
 {
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
 
@@ -156,6 +156,9 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
 #pragma unroll
         for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) t += s_wave_cnt[i];
         partials[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        /* a launch of tens of thousands of blocks is summed by several blocks of kmp_reduce_kernel, each of which ADDS its share
+         * to the pattern's counter: unless the pass accumulates, the counter starts from 0 here, a kernel boundary ahead of them */
+        if (zero_counts && blockIdx.x == 0u) zero_counts[pid] = 0ull;
     }
 }
 
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__restrict__ pkt_off,
                        const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,
                        const kmp_plan_entry *__restrict__ plan, const kmp_pattern_dev *__restrict__ patterns,
-                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, Emitter em,
+                       const uint32_t *__restrict__ pat_ids, unsigned long long *__restrict__ partials, unsigned long long *__restrict__ zero_counts, Emitter em,
                        uint32_t pad_clean)
 {
     __shared__ unsigned long long s_wave_cnt[KMP_BLOCK_WAVES];
@@ -360,6 +363,9 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
 #pragma unroll
         for (uint32_t i = 0; i < KMP_BLOCK_WAVES; ++i) t += s_wave_cnt[i];
         partials[(uint64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        /* a launch of tens of thousands of blocks is summed by several blocks of kmp_reduce_kernel, each of which ADDS its share
+         * to the pattern's counter: unless the pass accumulates, the counter starts from 0 here, a kernel boundary ahead of them */
+        if (zero_counts && blockIdx.x == 0u) zero_counts[pid] = 0ull;
     }
 }
 
@@ -381,7 +387,7 @@ hipError_t launch_flat_t(const kmp_scan_args &a, hipStream_t st)
 {
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
     const Emitter em = emitter_of(a);
-#define KMP_FLAT_ARGS a.arena, a.n_pkts, a.uniform_stride, a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials, em
+#define KMP_FLAT_ARGS a.arena, a.n_pkts, a.uniform_stride, a.uniform_len, a.pkts_per_wave, a.patterns, a.pat_ids, a.partials, a.zero_counts, em
     if (a.emit_out)
         hipLaunchKernelGGL((kmp_scan_flat_kernel<4, true, true>), grid, block, 0, st, KMP_FLAT_ARGS);
     else if (a.nontemporal)
@@ -400,7 +406,7 @@ hipError_t launch_packed_t(const kmp_scan_args &a, hipStream_t st)
     dim3 grid(a.blocks_x, a.n_ids), block(KMP_BLOCK_THREADS);
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const Emitter em = emitter_of(a);
-#define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, em, (a.pad_clean ? 1u : 0u)
+#define KMP_PACKED_ARGS a.arena, a.pkt_off, a.pkt_len, a.bitmap, plan, a.patterns, a.pat_ids, a.partials, a.zero_counts, em, (a.pad_clean ? 1u : 0u)
     if (a.emit_out)
         hipLaunchKernelGGL((kmp_scan_packed_kernel<4, true, true>), grid, block, 0, st, KMP_PACKED_ARGS);
     else if (a.nontemporal)

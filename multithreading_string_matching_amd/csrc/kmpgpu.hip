@@ -83,8 +83,6 @@ struct kmpgpu_ctx {
     std::vector<FusedGroup> fused_groups;
     uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
     uint32_t             *d_rest_ids = nullptr;      /* [rest_long + rest_short] everything else, long first  */
-    unsigned long long   *d_red_scratch = nullptr;   /* [n_pat][KMP_REDUCE_SCRATCH_WORDS] slice sums of the two-level count reduce */
-    uint32_t             *d_red_tickets = nullptr;   /* [n_pat] its ticket counters, 0 between launches         */
     uint32_t              rest_long = 0, rest_short = 0;
 
     /* arena */
@@ -103,6 +101,16 @@ struct kmpgpu_ctx {
     uint32_t        uni_stride = 0, uni_len = 0;
     void           *owned_arena = nullptr, *owned_off = nullptr, *owned_len = nullptr;
     uint64_t        cap_arena = 0, cap_pkts = 0;      /* capacities of the owned buffers (reused by the next load) */
+    uint64_t        bitmap_cap = 0;                   /* words d_bitmap holds (kept from load to load: a streamed capture loads batch after batch) */
+    bool            bitmap_live = false;              /* d_bitmap describes the arena that is attached now */
+    /* scratch of kmpgpu_load_frames, kept between calls for the same reason (hipMalloc / hipFree per batch would synchronise
+     * the device under the other context's scan): the frames' bytes, their offsets / captured lengths, the scan workspace, the
+     * payloads' source offsets, the totals */
+    uint8_t        *fr_file = nullptr, *fr_ws = nullptr;
+    uint64_t       *fr_off = nullptr, *fr_src = nullptr;
+    uint32_t       *fr_cl = nullptr;
+    unsigned long long *fr_tot = nullptr;
+    uint64_t        fr_file_cap = 0, fr_off_cap = 0, fr_cl_cap = 0, fr_ws_cap = 0, fr_src_cap = 0;
 
     /* results */
     unsigned long long *d_partials = nullptr;
@@ -136,21 +144,21 @@ bool use_flat(const kmpgpu_ctx *c)
 {
     if (!c->uniform || c->mode != 0) return false;
     if (c->kernel_sel == 3) return true;
-    return c->kernel_sel == 0 && (c->uni_len >= 512u || !c->packed || !c->d_bitmap);
+    return c->kernel_sel == 0 && (c->uni_len >= 512u || !c->packed || !c->bitmap_live);
 }
 /* Fused multi-pattern pass: explicit (1) or automatic (2): from 2 unique eligible patterns on -- 0.24 ms against
  * 2 x 0.23 ms as streaming passes over 1.5 GB (profiles/r02_multipattern.txt); the 1-byte patterns that ride along
  * do not count, a set of one eligible pattern plus 1-byte patterns keeps its streaming passes. */
 bool use_fused(const kmpgpu_ctx *c)
 {
-    if (!c->packed || !c->d_bitmap || c->mode != 0 || c->kernel_sel == 1 || c->fused_groups.empty()) return false;
+    if (!c->packed || !c->bitmap_live || c->mode != 0 || c->kernel_sel == 1 || c->fused_groups.empty()) return false;
     if (c->fused == 1) return c->n_multi_unique >= 2;
     return c->fused == 2 && c->n_multi_unique >= 2;
 }
 
 bool use_packed(const kmpgpu_ctx *c)
 {
-    return c->packed && c->d_bitmap && c->mode == 0 && (c->kernel_sel == 2 || ((c->kernel_sel == 0 || c->kernel_sel == 3) && !use_flat(c)));
+    return c->packed && c->bitmap_live && c->mode == 0 && (c->kernel_sel == 2 || ((c->kernel_sel == 0 || c->kernel_sel == 3) && !use_flat(c)));
 }
 
 uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
@@ -241,8 +249,27 @@ void release_arena(kmpgpu_ctx *c, bool keep_buffers = false)
     c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
     c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
     c->uniform = false; c->packed = false; c->pad_clean = false; c->plan_waves = 0;
-    if (c->d_bitmap) (void)hipFree(c->d_bitmap);
-    c->d_bitmap = nullptr;
+    c->bitmap_live = false;                           /* the buffer itself (1/128 of an arena) is kept for the next arena */
+}
+
+/* a device buffer of at least `want` elements, kept between calls: grown (with an eighth of headroom) only when it is too small */
+template <typename T>
+hipError_t grow_buffer(T **p, uint64_t *cap, uint64_t want)
+{
+    if (*p && *cap >= want) return hipSuccess;
+    if (*p) { const hipError_t e = hipFree(*p); *p = nullptr; *cap = 0; if (e != hipSuccess) return e; }
+    const uint64_t take = want + want / 8 + 1;
+    const hipError_t e = hipMalloc((void **)p, (size_t)take * sizeof(T));
+    if (e == hipSuccess) *cap = take;
+    return e;
+}
+
+void release_frame_scratch(kmpgpu_ctx *c)
+{
+    for (void *p : {(void *)c->fr_file, (void *)c->fr_ws, (void *)c->fr_off, (void *)c->fr_src, (void *)c->fr_cl, (void *)c->fr_tot})
+        if (p) (void)hipFree(p);
+    c->fr_file = c->fr_ws = nullptr; c->fr_off = c->fr_src = nullptr; c->fr_cl = nullptr; c->fr_tot = nullptr;
+    c->fr_file_cap = c->fr_off_cap = c->fr_cl_cap = c->fr_ws_cap = c->fr_src_cap = 0;
 }
 
 /* An arena whose slots are not back to back (gaps, shuffled order) is copied once into a packed one owned
@@ -292,9 +319,15 @@ int prepare_packed(kmpgpu_ctx *c)
     if (rc) return rc;
     if (!c->packed || c->n_pkts == 0) return KMPGPU_OK;
     const size_t words = (size_t)(c->arena_bytes / KMP_CHUNK) + 32;      /* the group prefetch reads up to 2 * DEPTH + 1 words past the end */
-    HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
+    if (c->bitmap_cap < words) {
+        if (c->d_bitmap) HIP_TRY(hipFree(c->d_bitmap));
+        c->d_bitmap = nullptr; c->bitmap_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
+        c->bitmap_cap = words;
+    }
     HIP_TRY(hipMemsetAsync(c->d_bitmap, 0, words * sizeof(unsigned long long), c->stream));
     HIP_TRY(kmp_launch_build_bitmap(c->d_off, c->n_pkts, c->d_bitmap, c->stream));
+    c->bitmap_live = true;
     /* slot padding: checked once; cleared when the arena is the context's own copy, otherwise the packed
      * kernel keeps fetching offset and length of a candidate's payload from the index */
     const bool own = c->owned_arena && c->d_arena == (const uint8_t *)c->owned_arena;
@@ -396,7 +429,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             HIP_TRY(record(e0, e1));
             HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-            HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate, c->d_red_scratch, c->d_red_tickets));
+            HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate));
             ++nl;
             max_u = std::max(max_u, g.n_unique);
         }
@@ -413,13 +446,16 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             a.n_ids = n;
             a.partials = c->d_partials + (part_base + g.first + done) * bx;
             a.masked = g.masked;
+            /* tens of thousands of partials per pattern are added up by several blocks, which add to the counter: it starts from 0 */
+            const bool sliced = (flat || packed) && kmp_reduce_is_sliced(bx);
+            a.zero_counts = (sliced && !c->accumulate) ? d_out : nullptr;
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
             if (emit && !flat && !packed)
                 return fail(KMPGPU_EINVAL, "kmpgpu_scan_offsets: the arena could not be brought into the streaming kernels' layout");
             HIP_TRY(flat ? kmp_launch_scan_flat(a, c->stream) : packed ? kmp_launch_scan_packed(a, c->stream) : kmp_launch_scan(a, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
-            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream, nullptr, c->accumulate, c->d_red_scratch, c->d_red_tickets));
+            HIP_TRY(kmp_launch_reduce(a.partials, bx, a.pat_ids, n, d_out, c->stream, nullptr, c->accumulate, sliced));
             ++nl;
         }
     }
@@ -480,6 +516,8 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release_arena(c);
+    release_frame_scratch(c);
+    if (c->d_bitmap) (void)hipFree(c->d_bitmap);
     if (c->d_patterns) (void)hipFree(c->d_patterns);
     if (c->d_ids) (void)hipFree(c->d_ids);
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -487,8 +525,6 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_plan) (void)hipFree(c->d_plan);
     free_fused_groups(c);
     if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
-    if (c->d_red_scratch) (void)hipFree(c->d_red_scratch);
-    if (c->d_red_tickets) (void)hipFree(c->d_red_tickets);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -572,17 +608,12 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     if (c->d_patterns) { HIP_TRY(hipFree(c->d_patterns)); c->d_patterns = nullptr; }
     if (c->d_ids) { HIP_TRY(hipFree(c->d_ids)); c->d_ids = nullptr; }
     if (c->d_counts) { HIP_TRY(hipFree(c->d_counts)); c->d_counts = nullptr; }
-    if (c->d_red_scratch) { HIP_TRY(hipFree(c->d_red_scratch)); c->d_red_scratch = nullptr; }
-    if (c->d_red_tickets) { HIP_TRY(hipFree(c->d_red_tickets)); c->d_red_tickets = nullptr; }
     c->n_pat = n_pat; c->n_long = (uint32_t)ids_long.size(); c->n_short = (uint32_t)ids_short.size();
     const size_t np = n_pat ? n_pat : 1;
     HIP_TRY(hipMalloc(&c->d_patterns, np * sizeof(kmp_pattern_dev)));
     HIP_TRY(hipMalloc(&c->d_ids, np * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&c->d_counts, np * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->d_counts, 0, np * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&c->d_red_scratch, np * KMP_REDUCE_SCRATCH_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&c->d_red_tickets, np * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->d_red_tickets, 0, np * sizeof(uint32_t)));
     if (n_pat) {
         std::vector<uint32_t> ids(ids_long);
         ids.insert(ids.end(), ids_short.begin(), ids_short.end());
@@ -819,7 +850,7 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: ctx is NULL");
     if (n_frames && (!file_bytes || !frame_off || !frame_caplen)) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: NULL buffers");
     /* Only the bytes these frames span are uploaded: a shard of the frames (mpi_dumping.c:149-161 scatters shares, not
-     * the whole capture) costs its share of PCIe time and HBM, not the file's. */
+     * the whole capture) or a batch of a streamed capture (openmp_task.c:126-155) costs its share of PCIe time and HBM. */
     uint64_t span_lo = file_nbytes, span_hi = 0;
     for (uint64_t f = 0; f < n_frames; f++) {
         if (frame_off[f] > file_nbytes || frame_caplen[f] > file_nbytes - frame_off[f])
@@ -832,71 +863,64 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     const uint64_t span = span_hi - span_lo;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    release_arena(c);
+    release_arena(c, /* keep_buffers = */ true);        /* batch after batch: device buffers are reused when the next batch fits */
     c->last.h2d_ms = 0; c->last.h2d_bytes = 0;
     if (n_payloads) *n_payloads = 0;
     if (n_frames == 0) return KMPGPU_OK;
 
-    uint8_t *d_file = nullptr, *d_ws = nullptr;
-    uint64_t *d_foff = nullptr, *d_src = nullptr;
-    uint32_t *d_cl = nullptr;
-    unsigned long long *d_tot = nullptr;
-    int rc = KMPGPU_OK;
-    auto cleanup = [&]() {
-        if (d_file) (void)hipFree(d_file);
-        if (d_ws) (void)hipFree(d_ws);
-        if (d_foff) (void)hipFree(d_foff);
-        if (d_src) (void)hipFree(d_src);
-        if (d_cl) (void)hipFree(d_cl);
-        if (d_tot) (void)hipFree(d_tot);
-    };
-#define KMP_TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(KMPGPU_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
-    KMP_TRY2(hipMalloc(&d_file, span + 64));
-    const uint8_t *d_base = d_file;                     /* the frame offsets are uploaded relative to the span's first byte */
-    std::vector<uint64_t> rel;
+    /* scratch, grown on demand and kept (no hipMalloc / hipFree per batch: either synchronises the whole device) */
+    HIP_TRY(grow_buffer(&c->fr_file, &c->fr_file_cap, span + 64));
+    HIP_TRY(grow_buffer(&c->fr_off, &c->fr_off_cap, n_frames));
+    HIP_TRY(grow_buffer(&c->fr_cl, &c->fr_cl_cap, n_frames));
+    HIP_TRY(grow_buffer(&c->fr_ws, &c->fr_ws_cap, (uint64_t)kmp_extract_ws_bytes(n_frames)));
+    if (!c->fr_tot) HIP_TRY(hipMalloc(&c->fr_tot, 2 * sizeof(unsigned long long)));
+
+    std::vector<uint64_t> rel;                          /* the frame offsets are uploaded relative to the span's first byte */
     if (span_lo) {
         rel.resize(n_frames);
         for (uint64_t f = 0; f < n_frames; f++) rel[f] = frame_off[f] - span_lo;
         frame_off = rel.data();
     }
-    KMP_TRY2(hipMalloc(&d_foff, n_frames * sizeof(uint64_t)));
-    KMP_TRY2(hipMalloc(&d_cl, n_frames * sizeof(uint32_t)));
-    KMP_TRY2(hipMalloc(&d_ws, kmp_extract_ws_bytes(n_frames)));
-    KMP_TRY2(hipMalloc(&d_tot, 2 * sizeof(unsigned long long)));
-    KMP_TRY2(hipEventRecord(c->ev[0], c->stream));
-    KMP_TRY2(hipMemcpyAsync(d_file, file_bytes + span_lo, span, hipMemcpyHostToDevice, c->stream));
-    KMP_TRY2(hipMemcpyAsync(d_foff, frame_off, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    KMP_TRY2(hipMemcpyAsync(d_cl, frame_caplen, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    KMP_TRY2(hipEventRecord(c->ev[1], c->stream));
-    KMP_TRY2(kmp_launch_extract_phase1(d_base, d_foff, d_cl, n_frames, tcp, d_ws, d_tot, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fr_file, file_bytes + span_lo, span, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fr_off, frame_off, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fr_cl, frame_caplen, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(kmp_launch_extract_phase1(c->fr_file, c->fr_off, c->fr_cl, n_frames, tcp, c->fr_ws, c->fr_tot, c->stream));
     unsigned long long tot[2] = {0, 0};
-    KMP_TRY2(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
-    KMP_TRY2(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(tot, c->fr_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0;
-    KMP_TRY2(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->last.h2d_ms = ms;
     c->last.h2d_bytes = span + n_frames * (sizeof(uint64_t) + sizeof(uint32_t));
     const uint64_t n_pkts = tot[1], arena_bytes = tot[0] + 64;
-    if (n_pkts) {
-        KMP_TRY2(hipMalloc(&c->owned_arena, arena_bytes));
-        KMP_TRY2(hipMalloc(&c->owned_off, n_pkts * sizeof(uint64_t)));
-        KMP_TRY2(hipMalloc(&c->owned_len, n_pkts * sizeof(uint32_t)));
-        KMP_TRY2(hipMalloc(&d_src, n_pkts * sizeof(uint64_t)));
-        c->cap_arena = arena_bytes; c->cap_pkts = n_pkts;
-        KMP_TRY2(hipMemsetAsync((uint8_t *)c->owned_arena + tot[0], 0, 64, c->stream));
-        KMP_TRY2(kmp_launch_extract_phase2(d_base, d_foff, n_frames, d_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
-                                           (uint32_t *)c->owned_len, d_src, c->stream));
-        KMP_TRY2(hipStreamSynchronize(c->stream));
-    }
-#undef KMP_TRY2
-    cleanup();
     if (n_payloads) *n_payloads = n_pkts;
     if (n_pkts == 0) return KMPGPU_OK;
+    if (!(c->owned_arena && c->cap_arena >= arena_bytes && c->cap_pkts >= n_pkts)) {
+        if (c->owned_arena) HIP_TRY(hipFree(c->owned_arena));
+        if (c->owned_off) HIP_TRY(hipFree(c->owned_off));
+        if (c->owned_len) HIP_TRY(hipFree(c->owned_len));
+        c->owned_arena = c->owned_off = c->owned_len = nullptr; c->cap_arena = c->cap_pkts = 0;
+        const uint64_t take_b = arena_bytes + arena_bytes / 8, take_n = n_pkts + n_pkts / 8;
+        HIP_TRY(hipMalloc(&c->owned_arena, take_b));
+        HIP_TRY(hipMalloc(&c->owned_off, take_n * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&c->owned_len, take_n * sizeof(uint32_t)));
+        c->cap_arena = take_b; c->cap_pkts = take_n;
+    }
+    HIP_TRY(grow_buffer(&c->fr_src, &c->fr_src_cap, n_pkts));
+    HIP_TRY(hipMemsetAsync((uint8_t *)c->owned_arena + tot[0], 0, 64, c->stream));
+    HIP_TRY(kmp_launch_extract_phase2(c->fr_file, c->fr_off, n_frames, c->fr_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
+                                      (uint32_t *)c->owned_len, c->fr_src, c->stream));
     c->d_arena = (const uint8_t *)c->owned_arena;
     c->d_off = (const uint64_t *)c->owned_off;
     c->d_len = (const uint32_t *)c->owned_len;
     c->arena_bytes = arena_bytes; c->n_pkts = n_pkts;
-    return finish_device_index(c, "kmpgpu_load_frames");
+    const int rc = finish_device_index(c, "kmpgpu_load_frames");
+    /* one capture uploaded whole: its bytes are not kept around (a streamed capture's batches are small and the next one
+     * reuses the buffer) */
+    if (c->fr_file_cap > (1ull << 30)) { (void)hipFree(c->fr_file); c->fr_file = nullptr; c->fr_file_cap = 0; }
+    return rc;
 }
 
 int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes, const void *d_pkt_off,

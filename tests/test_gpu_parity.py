@@ -877,17 +877,25 @@ def test_cli_openmp_data_form(fixture_counts, tokens, shards):
     assert r.returncode == 0 and _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
 
 
-@pytest.mark.parametrize("shards,batch", [("1", "1048576"), ("2", "1048576"), ("3", "67108864")])
+@pytest.mark.parametrize("extract", ["0", "1"])
+@pytest.mark.parametrize("shards,batch", [("1", "1048576"), ("2", "65536"), ("3", "67108864")])
 @pytest.mark.parametrize("key", ["big_udp.pcap:udp", "very_big_udp.pcap:udp", "udp_1000.pcap:tcp"])
-def test_cli_openmp_task_streaming(fixture_counts, tokens, key, shards, batch):
-    """bin/openmp_task: batches of the capture scanned while the next ones are read (openmp_task.c:126-186)."""
+def test_cli_openmp_task_streaming(fixture_counts, tokens, key, shards, batch, extract):
+    """bin/openmp_task: batches of the capture scanned while the next ones are read (openmp_task.c:126-186); with
+    KMPGPU_DEVICE_EXTRACT=1 the batches are RAW frames of the mapped capture and the payloads are extracted on the GPU
+    (packet_dumping.h:87-188 on the device): same report, same payloads, no host copy."""
     fx = fixture_counts["fixtures"][key]
     exe = os.path.join(_lib.BINDIR, "openmp_task")
-    env = dict(os.environ, KMPGPU_BATCH_BYTES=batch)
+    env = dict(os.environ, KMPGPU_BATCH_BYTES=batch, KMPGPU_DEVICE_EXTRACT=extract)
     r = subprocess.run([exe, os.path.join(DATA, fx["pcap"]), os.path.join(DATA, "strings.txt"), shards, fx["mode"]],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert _strip_elapsed(r.stdout) == K.format_report(tokens, fx["counts"])
+    assert f"streamed {fx['packets']} frames, {fx['payloads']} payloads, {fx['payload_bytes']} payload bytes in " in r.stderr, r.stderr
+    nb = int(r.stderr.split(" payload bytes in ")[1].split()[0])
+    volume = os.path.getsize(os.path.join(DATA, fx["pcap"])) if extract == "1" else fx["payload_bytes"]      # what a batch is measured in
+    assert nb >= volume // int(batch), r.stderr          # the capture really went through in batches (64 KiB ones: 6 to 29 of them)
+    assert ("raw frames, extraction on the GPU" in r.stderr) == (extract == "1")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -212,6 +212,46 @@ def test_batch_reader_equals_whole_arena(cap_bytes, cap_pkts):
     assert batches > 1 or cap_bytes >= whole.nbytes
 
 
+@pytest.mark.parametrize("pcap", ["udp_1000.pcap", "tcp.pcap", "big_udp.pcap"])
+@pytest.mark.parametrize("span,cap", [(1 << 20, 1 << 16), (4096, 1 << 16), (1 << 20, 7), (64, 5)])
+def test_frame_batches_equal_the_frame_index(pcap, span, cap):
+    """The producer of openmp_task.c:126-155 with the extraction left to the GPU: the frame batches together are exactly
+    the records kmp_frames_from_pcap finds, in order, every batch within its span (one oversized record may stand alone),
+    located inside the mapped capture itself."""
+    import ctypes as C
+    L = _lib.host_lib()
+    path = os.path.join(DATA, pcap).encode()
+    err = C.create_string_buffer(256)
+    fr = _lib.Frames()
+    assert L.kmp_frames_from_pcap(path, None, None, C.byref(fr), err) == 0
+    want = [(int(fr.off[i]), int(fr.caplen[i])) for i in range(fr.n)]
+    raw = open(os.path.join(DATA, pcap), "rb").read()
+    rd = L.kmp_batch_open(path, 0, err)
+    assert rd
+    nb = C.c_uint64()
+    base = L.kmp_batch_file(rd, C.byref(nb))
+    assert nb.value == len(raw) and C.string_at(base, 64) == raw[:64]
+    off = np.zeros(cap, dtype=np.uint64)
+    cl = np.zeros(cap, dtype=np.uint32)
+    got, batches = [], 0
+    while True:
+        n = L.kmp_batch_next_frames(rd, span, off.ctypes.data, cl.ctypes.data, cap)
+        assert n >= 0
+        if n == 0:
+            break
+        batches += 1
+        assert n <= cap
+        lo, hi = int(off[0]), int(off[n - 1]) + int(cl[n - 1])
+        assert n == 1 or hi - lo <= span
+        got += [(int(off[k]), int(cl[k])) for k in range(n)]
+    assert L.kmp_batch_next_frames(rd, span, off.ctypes.data, cl.ctypes.data, cap) == 0      # stays at the end
+    L.kmp_batch_close(rd)
+    L.kmp_frames_free(C.byref(fr))
+    assert got == want and (batches > 1 or span >= len(raw))
+    for o, c in got[:50]:
+        assert o + c <= len(raw)
+
+
 def test_arena_from_payloads_roundtrip():
     pls = [b"", b"x", b"hello world", b"a" * 16, b"b" * 17, b"", b"c" * 5000]
     a = K.HostArena.from_payloads(pls)

@@ -233,6 +233,27 @@ __global__ void __launch_bounds__(256) read_range_t(const u32x4 *__restrict__ sr
     if (lane == 0) tend[gw] = __builtin_amdgcn_s_memrealtime();
 }
 
+// round 3: the shape the scan kernel has had since the end of round 2 -- SMALL contiguous ranges, one 256-thread block per four of
+// them, as many blocks as that takes (62 500 for the benchmark arena), handed out in arena order by the hardware: what does a
+// kernel reach that only READS with that shape?  per16 = range in 16-byte units (376 = four 1504-byte slots).
+template <int INFL, bool NT>
+__global__ void __launch_bounds__(256) read_small(const u32x4 *__restrict__ src, uint64_t n16, uint32_t per16, uint32_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t gw = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t b = gw * per16, e = std::min<uint64_t>(n16, b + per16);
+    u32x4 acc = {0, 0, 0, 0};
+    const u32x4 z = {0, 0, 0, 0};
+    for (uint64_t c = b; c < e; c += 64u * INFL) {
+        u32x4 v[INFL];
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) { const uint64_t k = c + 64u * i + lane; v[i] = k < e ? ld16<NT>(src + k) : z; }
+#pragma unroll
+        for (int i = 0; i < INFL; ++i) acc ^= v[i];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
 template <typename F> double sustained_us(F launch)
 {
     const int warm = 60, n = 100;
@@ -281,6 +302,15 @@ int main()
         printf("ranges from %4d counters, %2d per wavefront   blocks/CU=4  %7.1f us  %6.0f GB/s\n", G, parts, us2, bytes / us2 / 1e3); fflush(stdout); } while (0)
         for (int parts : {2, 3, 4, 8}) { STEAL(64, parts); STEAL(256, parts); STEAL(1024, parts); }
     }
+    // round 3: small ranges, non-persistent grid (the scan kernel's shape since the end of round 2)
+    for (uint32_t per16 : {188u, 376u, 752u, 1504u, 3008u}) {
+        const uint64_t waves = (n16 + per16 - 1) / per16;
+        const int b_ = (int)((waves + 3) / 4);
+#define RUNS(INFL) do { double us = sustained_us([&] { hipLaunchKernelGGL((read_small<INFL, true>), dim3(b_), dim3(256), 0, 0, s, n16, per16, out); }); \
+        printf("small ranges of %5u B per wavefront, %6d blocks, %d x 1 KiB in flight nt   %7.1f us  %6.0f GB/s\n", per16 * 16u, b_, INFL, us, bytes / us / 1e3); fflush(stdout); } while (0)
+        RUNS(2); RUNS(3); RUNS(6);
+    }
+    if (getenv("READBW_SMALL_ONLY")) return 0;
     // block size: the same 3072 / 4096 wavefronts as 64..1024-thread workgroups
     for (int waves : {3072, 4096}) {
 #define RUNBS(BS) do { const int b_ = waves * 64 / BS; double us = sustained_us([&] { hipLaunchKernelGGL((read_range_bs<4, true, BS>), dim3(b_), dim3(BS), 0, 0, s, n16, out); }); \
