@@ -109,6 +109,11 @@ int  kmpgpu_set_option(kmpgpu_ctx *ctx, int key, int64_t value);
 /* Pinned host memory for the arena (north_star: "pinned contiguous arena"). */
 void *kmpgpu_host_alloc(size_t bytes);
 void  kmpgpu_host_free(void *p);
+/* Pin memory the caller already has -- e.g. (a window of) a capture file's read-only mapping -- so that uploads from it
+ * (kmpgpu_load_frames, kmpgpu_load_arena) run as asynchronous DMA at PCIe speed instead of being staged through the runtime's
+ * bounce buffers.  ptr page-aligned.  Returns KMPGPU_EHIP where the runtime refuses (then the memory simply stays pageable). */
+int   kmpgpu_host_register(const void *ptr, size_t bytes);
+int   kmpgpu_host_unregister(const void *ptr);
 
 /* Replaces array_of_strings + prefix_array construction, serial.c:148-152 (kmp_prefix for every
  * pattern): copies the patterns, builds the failure tables on the host, uploads both.
@@ -137,6 +142,12 @@ int  kmpgpu_load_arena(kmpgpu_ctx *ctx, const uint8_t *arena, uint64_t arena_byt
  * the context's arena.  tcp: 0 = UDP rule, 1 = TCP rule.  *n_payloads = payloads accepted. */
 int  kmpgpu_load_frames(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
                         const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads);
+
+/* Size the context's device buffers ahead of time for arenas of up to arena_bytes / n_pkts payloads and, when frame_bytes != 0, for
+ * kmpgpu_load_frames calls of up to frame_bytes of capture / n_frames frames: a streamed capture (openmp_task.c:126-186) loads batch
+ * after batch into the same buffers, and the first batch should not pay for a dozen device allocations.  Optional: every loader
+ * grows what it needs. */
+int  kmpgpu_reserve(kmpgpu_ctx *ctx, uint64_t arena_bytes, uint64_t n_pkts, uint64_t frame_bytes, uint64_t n_frames);
 
 /* Same, for an arena already resident in device memory (borrowed; same contract, checked by a
  * device-side pass; an arena that is not packed is copied unless KMPGPU_OPT_REPACK is 0).  d_arena: uint8_t*, d_pkt_off: uint64_t*, d_pkt_len: uint32_t*.

@@ -138,10 +138,13 @@ int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, 
 /* The same producer with the extraction left to the GPU (kmpgpu_load_frames): the next records of the capture whose bytes
  * span at most max_span_bytes of the file (at least one record, at most cap_frames).  Only the record headers are read;
  * frame_off[f] / frame_caplen[f] locate the frames inside the buffer kmp_batch_file() returns (the mapped capture itself:
- * nothing is copied).  Returns the number of frames (0 = end of capture).  A reader serves either kind of batch, not both. */
+ * nothing is copied here).  Returns the number of frames (0 = end of capture).  A reader serves either kind of batch, not both. */
 int64_t kmp_batch_next_frames(kmp_batch_reader *r, uint64_t max_span_bytes, uint64_t *frame_off, uint32_t *frame_caplen,
                               uint64_t cap_frames);
 const uint8_t *kmp_batch_file(const kmp_batch_reader *r, uint64_t *nbytes);
+/* memcpy by several threads (the CPUs this process may use, at most 16; KMPHOST_THREADS): stages a batch of raw frames from the mapped
+ * capture into a pinned buffer -- one bulk copy per batch, no per-packet work. */
+void kmp_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n);
 void kmp_batch_close(kmp_batch_reader *r);
 
 /* Synthetic fill on the host (same bytes as the device generator, kmp_synth.h). */

@@ -106,6 +106,7 @@ HOST_API = {
     "kmp_batch_next": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p]),
     "kmp_batch_next_frames": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
     "kmp_batch_file": (C.c_void_p, [C.c_void_p, u64p]),
+    "kmp_copy_bytes": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "kmp_batch_close": (None, [C.c_void_p]),
     "kmp_synth_fill_host": (None, [u8p, u64p, u32p, C.c_uint64, C.c_uint64, C.POINTER(SynthParams), C.c_int]),
     "kmp_synth_count_planted": (C.c_uint64, [u32p, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(SynthParams)]),
@@ -123,8 +124,11 @@ GPU_API = {
     "kmpgpu_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "kmpgpu_host_alloc": (C.c_void_p, [C.c_size_t]),
     "kmpgpu_host_free": (None, [C.c_void_p]),
+    "kmpgpu_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "kmpgpu_host_unregister": (C.c_int, [C.c_void_p]),
     "kmpgpu_set_patterns": (C.c_int, [C.c_void_p, C.POINTER(u8p), u32p, C.c_uint32]),
     "kmpgpu_load_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "kmpgpu_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "kmpgpu_load_frames": (C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, u32p, C.c_uint64, C.c_int, u64p]),
     "kmpgpu_arena_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p, C.c_void_p]),
     "kmpgpu_attach_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),

@@ -6,14 +6,17 @@
  * openmp_task.c:126-186 lets one thread read the capture 100 packets at a time and spawns a task per
  * batch; the tasks add their private counters into the shared ones.  Here the producer (this thread)
  * reads batches of KMPGPU_BATCH_BYTES (default 64 MiB) into pinned buffers while consumer threads,
- * one per GPU shard (thread_number), upload and scan them: pcap read || H2D || scan.  Every consumer
- * alternates between two contexts (own stream, own device buffers) so that the upload of a batch
+ * two per GPU shard (thread_number), upload and scan them: pcap read || H2D || scan.  Every consumer
+ * has a context of its own (own stream, own device buffers) so that the upload of a batch
  * overlaps the scan of the previous one; the contexts accumulate counts over their batches
  * (KMPGPU_OPT_ACCUMULATE) and the totals are summed at the end (openmp_task.c:172-175).
  *
  * KMPGPU_DEVICE_EXTRACT=1 (SURVEY 8(f) N2 x N3): the producer only walks the record headers of the mapped capture
- * (kmp_batch_next_frames) and the consumers upload the RAW frames of a batch straight from the mapping and extract the
- * payloads on the GPU (kmpgpu_load_frames, packet_dumping.h:87-188 on the device): no payload is copied on the host.
+ * (kmp_batch_next_frames); a second host thread stages the RAW bytes of a batch -- headers, frames, everything, one bulk
+ * copy by several threads -- into a pinned buffer while the producer walks the next batch; the consumers upload that
+ * buffer and extract the payloads on the GPU (kmpgpu_load_frames, packet_dumping.h:87-188 on the device).  No per-packet
+ * work on the host.  (Uploading straight from the mapping was measured and dropped: pageable pages go through the
+ * runtime's bounce buffers at 15 GB/s, and pinning them costs 55 ms per GB: profiles/r03_end_to_end_pinning_experiment.txt.)
  *
  * stdout is byte-compatible with the reference (openmp_task.c:190-196).  No CPU fallback: exit code 2
  * without a gfx950 device.
@@ -27,14 +30,15 @@
 #include "kmpgpu.h"
 #include "kmphost.h"
 
-#define SLOTS_PER_SHARD 3
+#define SLOTS_PER_SHARD 5               /* one being walked / read, one being staged, two being uploaded, one spare */
 
 typedef struct slot {
-    uint8_t  *arena;                 /* payload batches: pinned arena; frame batches: unused (the frames stay in the mapped capture) */
+    uint8_t  *arena;                 /* pinned: the payload arena of a batch / the raw bytes of a frame batch */
     uint64_t *off;                   /* payload offsets in arena / frame offsets in the capture */
     uint32_t *len;                   /* payload lengths / captured lengths of the frames       */
     uint64_t  used, n;
-    int       state;                 /* 0 free, 1 filled */
+    uint64_t  lo;                    /* frame batches: file offset of the batch's first staged byte */
+    int       state;                 /* 0 free, 1 filled (frame batches: 1 walked, 2 staged) */
 } slot;
 
 typedef struct shared {
@@ -44,6 +48,9 @@ typedef struct shared {
     int             n_slots;
     int             done;            /* producer finished */
     uint64_t        next_fill, next_take;     /* ring positions */
+    uint64_t        next_walk, next_copy;     /* frame batches: walked / staged so far */
+    int             walked_all;
+    double          copy_s;
     const kmp_patterns *pats;
     const uint8_t **pp;
     int             ndev;
@@ -53,6 +60,7 @@ typedef struct shared {
     int             frames_mode, tcp;
     const uint8_t  *file;
     uint64_t        file_bytes;
+    uint64_t        batch_bytes, cap_pkts;
 } shared;
 
 typedef struct consumer {
@@ -61,6 +69,7 @@ typedef struct consumer {
     kmpgpu_ctx *total;               /* the context that holds this shard's counts when the consumer is done */
     double    kernel_ms, h2d_ms;
     uint64_t  batches, payloads, bytes;
+    double    load_s, wait_s;        /* time inside the load calls / waiting for a filled slot */
 } consumer;
 
 static double now_s(void)
@@ -76,42 +85,77 @@ static void die_gpu(const char *what)
     exit(2);
 }
 
+/* KMPGPU_DEVICE_EXTRACT=1, second stage: the raw bytes of a walked batch go from the mapped capture into the slot's pinned buffer
+ * (kmp_copy_bytes: several threads), the frame offsets are rebased to that buffer, and the batch is handed to the consumers. */
+static void *stage_batches(void *arg)
+{
+    shared *sh = (shared *)arg;
+    for (;;) {
+        pthread_mutex_lock(&sh->mu);
+        while (sh->next_copy == sh->next_walk && !sh->walked_all) pthread_cond_wait(&sh->cv, &sh->mu);
+        if (sh->next_copy == sh->next_walk && sh->walked_all) {
+            sh->done = 1;
+            pthread_cond_broadcast(&sh->cv);
+            pthread_mutex_unlock(&sh->mu);
+            return NULL;
+        }
+        slot *s = &sh->slots[sh->next_copy % (uint64_t)sh->n_slots];
+        pthread_mutex_unlock(&sh->mu);
+        const double t0 = now_s();
+        kmp_copy_bytes(s->arena, sh->file + s->lo, s->used);
+        for (uint64_t k = 0; k < s->n; k++) s->off[k] -= s->lo;
+        pthread_mutex_lock(&sh->mu);
+        sh->copy_s += now_s() - t0;
+        s->state = 2;
+        sh->next_copy++;
+        sh->next_fill++;
+        pthread_cond_broadcast(&sh->cv);
+        pthread_mutex_unlock(&sh->mu);
+    }
+}
+
 static void *consume(void *arg)
 {
     consumer *me = (consumer *)arg;
     shared *sh = me->sh;
-    kmpgpu_ctx *ctx[2] = {NULL, NULL};
-    for (int i = 0; i < 2; i++) {
-        if (kmpgpu_init(&ctx[i], me->id % sh->ndev)) die_gpu("kmpgpu_init");
-        if (kmpgpu_set_patterns(ctx[i], sh->pp, sh->pats->len, sh->pats->n)) die_gpu("kmpgpu_set_patterns");
-        if (kmpgpu_set_option(ctx[i], KMPGPU_OPT_ACCUMULATE, 1) || kmpgpu_counts_reset(ctx[i])) die_gpu("kmpgpu_set_option");
-        if (kmpgpu_sync(ctx[i])) die_gpu("kmpgpu_sync");
-    }
-    pthread_mutex_lock(&sh->mu);                               /* the contexts are up: the clock may start (main waits for every consumer) */
+    /* one context (own stream, own device buffers) per consumer thread, TWO threads per GPU shard: while one of them is inside a load
+     * call -- upload, extraction, the few synchronisations in between --, the other one's upload is already under way, and the scans
+     * run behind both (round 2 alternated two contexts from ONE thread: the copy engine idled whenever that thread waited) */
+    kmpgpu_ctx *c = NULL;
+    if (kmpgpu_init(&c, (me->id / 2) % sh->ndev)) die_gpu("kmpgpu_init");
+    if (kmpgpu_set_patterns(c, sh->pp, sh->pats->len, sh->pats->n)) die_gpu("kmpgpu_set_patterns");
+    if (kmpgpu_set_option(c, KMPGPU_OPT_ACCUMULATE, 1) || kmpgpu_counts_reset(c)) die_gpu("kmpgpu_set_option");
+    /* the device buffers of a batch, once: the first batch does not pay for a dozen allocations under the clock */
+    if (kmpgpu_reserve(c, sh->batch_bytes + 64, sh->cap_pkts, sh->frames_mode ? sh->batch_bytes + 64 : 0, sh->frames_mode ? sh->cap_pkts : 0)) die_gpu("kmpgpu_reserve");
+    if (kmpgpu_sync(c)) die_gpu("kmpgpu_sync");
+    me->total = c;
+    pthread_mutex_lock(&sh->mu);                               /* the context is up: the clock may start (main waits for every consumer) */
     sh->ready++;
     pthread_cond_broadcast(&sh->cv);
     pthread_mutex_unlock(&sh->mu);
-    int turn = 0;
     for (;;) {
+        const double tw0 = now_s();
         pthread_mutex_lock(&sh->mu);
         while (sh->next_take == sh->next_fill && !sh->done) pthread_cond_wait(&sh->cv, &sh->mu);
+        me->wait_s += now_s() - tw0;
         if (sh->next_take == sh->next_fill && sh->done) { pthread_mutex_unlock(&sh->mu); break; }
         slot *s = &sh->slots[sh->next_take % (uint64_t)sh->n_slots];
         sh->next_take++;
         pthread_mutex_unlock(&sh->mu);
 
-        kmpgpu_ctx *c = ctx[turn];
-        turn ^= 1;
-        /* waits for this context's previous scan, uploads (the other context's scan keeps running) */
+        /* waits for this context's previous scan, uploads (the other contexts' work keeps running) */
+        const double tl0 = now_s();
         if (sh->frames_mode) {
             uint64_t np = 0, pb = 0;
-            if (kmpgpu_load_frames(c, sh->file, sh->file_bytes, s->off, s->len, s->n, sh->tcp, &np)) die_gpu("kmpgpu_load_frames");
+            if (kmpgpu_load_frames(c, s->arena, s->used, s->off, s->len, s->n, sh->tcp, &np)) die_gpu("kmpgpu_load_frames");
             kmpgpu_arena_info(c, NULL, &pb);
             me->payloads += np; me->bytes += np ? pb : 0;
         } else {
             if (kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n)) die_gpu("kmpgpu_load_arena");
             me->payloads += s->n;
         }
+        me->load_s += now_s() - tl0;
+        { kmpgpu_timing tt; if (kmpgpu_last_timing(c, &tt) == 0) me->h2d_ms += tt.h2d_ms; }
         me->batches++;
         pthread_mutex_lock(&sh->mu);
         s->state = 0;                                        /* the pinned buffer may be refilled */
@@ -119,12 +163,7 @@ static void *consume(void *arg)
         pthread_mutex_unlock(&sh->mu);
         if (kmpgpu_scan_enqueue(c, NULL)) die_gpu("kmpgpu_scan_enqueue");
     }
-    /* the two contexts' running totals are merged on the device (openmp_task.c:172-175); the shard's counters stay there
-     * for the reduce over the shards */
-    if (kmpgpu_counts_add(ctx[0], ctx[1])) die_gpu("kmpgpu_counts_add");
-    if (kmpgpu_sync(ctx[0])) die_gpu("kmpgpu_sync");
-    kmpgpu_destroy(ctx[1]);
-    me->total = ctx[0];
+    if (kmpgpu_sync(c)) die_gpu("kmpgpu_sync");
     return NULL;
 }
 
@@ -176,42 +215,60 @@ int main(int argc, char *argv[])
     sh.slots = (slot *)calloc((size_t)sh.n_slots, sizeof(slot));
     sh.pats = &pats; sh.ndev = ndev;
     sh.frames_mode = frames_mode; sh.tcp = proto == KMP_PROTO_TCP;
+    sh.batch_bytes = batch_bytes; sh.cap_pkts = cap_pkts;
     sh.file = kmp_batch_file(rd, &sh.file_bytes);
     sh.pp = (const uint8_t **)malloc(sizeof(uint8_t *) * (pats.n ? pats.n : 1));
     for (uint32_t i = 0; i < pats.n; i++) sh.pp[i] = pats.blob + pats.off[i];
     for (int i = 0; i < sh.n_slots; i++) {
-        sh.slots[i].arena = frames_mode ? NULL : (uint8_t *)kmpgpu_host_alloc((size_t)batch_bytes);
+        sh.slots[i].arena = (uint8_t *)kmpgpu_host_alloc((size_t)batch_bytes + 64);
         sh.slots[i].off = (uint64_t *)kmpgpu_host_alloc((size_t)cap_pkts * sizeof(uint64_t));
         sh.slots[i].len = (uint32_t *)kmpgpu_host_alloc((size_t)cap_pkts * sizeof(uint32_t));
-        if ((!frames_mode && !sh.slots[i].arena) || !sh.slots[i].off || !sh.slots[i].len) die_gpu("kmpgpu_host_alloc");
+        if (!sh.slots[i].arena || !sh.slots[i].off || !sh.slots[i].len) die_gpu("kmpgpu_host_alloc");
     }
 
     /* The consumers and their GPU contexts (streams, pattern tables) are set up before the clock starts, like the pinned
      * buffers above and like everything openmp_task.c does before :124 (pattern load, pcap_open_offline, allocations). */
-    consumer *cons = (consumer *)calloc((size_t)shards, sizeof(consumer));
-    pthread_t *th = (pthread_t *)calloc((size_t)shards, sizeof(pthread_t));
+    const int n_cons = 2 * shards;                                                                  /* two consumer threads (contexts) per GPU shard */
+    consumer *cons = (consumer *)calloc((size_t)n_cons, sizeof(consumer));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_cons, sizeof(pthread_t));
     if (pats.n) {
-        for (int r = 0; r < shards; r++) {
+        for (int r = 0; r < n_cons; r++) {
             cons[r].sh = &sh; cons[r].id = r;
-            pthread_create(&th[r], NULL, consume, &cons[r]);
+            if (pthread_create(&th[r], NULL, consume, &cons[r]) != 0) { fprintf(stderr, "cannot start a consumer thread\n"); exit(2); }
         }
         pthread_mutex_lock(&sh.mu);
-        while (sh.ready < shards) pthread_cond_wait(&sh.cv, &sh.mu);
+        while (sh.ready < n_cons) pthread_cond_wait(&sh.cv, &sh.mu);
         pthread_mutex_unlock(&sh.mu);
     }
     const double t_start = now_s();                                                                 /* openmp_task.c:124 */
+    pthread_t stage_th;
+    const int staging = frames_mode && pats.n && pthread_create(&stage_th, NULL, stage_batches, &sh) == 0;
+    if (frames_mode && pats.n && !staging) { fprintf(stderr, "cannot start the staging thread\n"); exit(2); }
     uint64_t frames = 0, payloads = 0, bytes = 0, batches = 0;
+    double prod_walk_s = 0, prod_wait_s = 0;
     for (;;) {                                                                                      /* openmp_task.c:130-155: the producer */
-        slot *s = &sh.slots[sh.next_fill % (uint64_t)sh.n_slots];
+        slot *s = &sh.slots[(frames_mode ? sh.next_walk : sh.next_fill) % (uint64_t)sh.n_slots];
+        const double tp0 = now_s();
         pthread_mutex_lock(&sh.mu);
         while (s->state != 0) pthread_cond_wait(&sh.cv, &sh.mu);
         pthread_mutex_unlock(&sh.mu);
+        const double tp1 = now_s();
+        prod_wait_s += tp1 - tp0;
+        /* the first batches are small (8, 16, 32 MiB ...): the upload of the first one starts a millisecond sooner */
+        uint64_t this_batch = batch_bytes;
+        if (batches < 4 && ((8ull << 20) << batches) < batch_bytes) this_batch = (8ull << 20) << batches;
         int64_t n;
         if (frames_mode) {
-            n = kmp_batch_next_frames(rd, batch_bytes, s->off, s->len, cap_pkts);                   /* record headers only */
-            if (n > 0) frames += (uint64_t)n;
+            n = kmp_batch_next_frames(rd, this_batch, s->off, s->len, cap_pkts);                    /* record headers only */
+            if (n > 0) {
+                frames += (uint64_t)n;
+                s->lo = s->off[0] & ~(uint64_t)15;                                                  /* (keeps the frames' alignment in the staged copy) */
+                s->used = s->off[n - 1] + s->len[n - 1] - s->lo;
+                if (s->used > batch_bytes + 64) n = -1;                                             /* one record larger than a batch */
+            }
         } else
-            n = kmp_batch_next(rd, s->arena, batch_bytes, s->off, s->len, cap_pkts, &s->used, &frames);
+            n = kmp_batch_next(rd, s->arena, this_batch, s->off, s->len, cap_pkts, &s->used, &frames);
+        prod_walk_s += now_s() - tp1;
         if (n < 0) { fprintf(stderr, "error reading pcap file: a payload exceeds KMPGPU_BATCH_BYTES\n"); exit(1); }
         if (n == 0) break;
         s->n = (uint64_t)n;
@@ -223,23 +280,32 @@ int main(int argc, char *argv[])
         if (!pats.n) continue;
         pthread_mutex_lock(&sh.mu);
         s->state = 1;
-        sh.next_fill++;
+        if (frames_mode) sh.next_walk++;             /* on to the staging thread, which hands it to the consumers */
+        else sh.next_fill++;
         pthread_cond_broadcast(&sh.cv);
         pthread_mutex_unlock(&sh.mu);
     }
     pthread_mutex_lock(&sh.mu);
-    sh.done = 1;
+    if (staging) sh.walked_all = 1;                  /* the staging thread announces the end once it has caught up */
+    else sh.done = 1;
     pthread_cond_broadcast(&sh.cv);
     pthread_mutex_unlock(&sh.mu);
+    if (staging) pthread_join(stage_th, NULL);
 
     uint64_t *counts = (uint64_t *)calloc(pats.n ? pats.n : 1, sizeof(uint64_t));
     int reduce_rccl = 0;
     if (pats.n) {
         kmpgpu_ctx **tot = (kmpgpu_ctx **)calloc((size_t)shards, sizeof *tot);
-        for (int r = 0; r < shards; r++) {
+        for (int r = 0; r < n_cons; r++) {
             pthread_join(th[r], NULL);
-            tot[r] = cons[r].total;
             if (frames_mode) { payloads += cons[r].payloads; bytes += cons[r].bytes; }              /* what the GPUs extracted */
+        }
+        for (int r = 0; r < shards; r++) {
+            /* a shard's two contexts' running totals are merged on the device (openmp_task.c:172-175); the shard's counters stay
+             * there for the reduce over the shards */
+            if (kmpgpu_counts_add(cons[2 * r].total, cons[2 * r + 1].total)) die_gpu("kmpgpu_counts_add");
+            if (kmpgpu_sync(cons[2 * r].total)) die_gpu("kmpgpu_sync");
+            tot[r] = cons[2 * r].total;
         }
         /* The sum over the shards (mpi_dumping.c:202): one shard per device -> RCCL all-reduce of the device counters and
          * one download; shards that share a device -> host sum.  KMPGPU_RCCL=0 / 1 as in bin/openmp_data. */
@@ -265,7 +331,6 @@ int main(int argc, char *argv[])
             }
         }
         free(part);
-        for (int r = 0; r < shards; r++) kmpgpu_destroy(tot[r]);
         free(tot);
     }
     const double t_finish = now_s();                                                                /* openmp_task.c:188 */
@@ -276,6 +341,16 @@ int main(int argc, char *argv[])
             (unsigned long long)(batch_bytes >> 20), frames_mode ? "raw frames, extraction on the GPU" : "payloads extracted on the host", shards, reduce_rccl ? "RCCL all-reduce" : (shards > 1 ? "host sum" : "none"), t_finish - t_start,
             (double)bytes / (t_finish - t_start) / 1e9);
 
+    { const char *st = getenv("KMPGPU_STATS");
+      if (st && st[0] && st[0] != '0') {
+          double load_s = 0, wait_s = 0, h2d = 0;
+          for (int r = 0; r < 2 * shards; r++) { load_s += cons[r].load_s; wait_s += cons[r].wait_s; h2d += cons[r].h2d_ms; }
+          fprintf(stderr, "[kmpgpu] phases: producer %.3f s building batches + %.3f s waiting for a free slot; staging copies %.3f s; consumers %.3f s in the load calls "
+                          "(uploads by the events: %.3f s), %.3f s waiting for a batch\n",
+                  prod_walk_s, prod_wait_s, sh.copy_s, load_s, h2d * 1e-3, wait_s);
+      } }
+    /* teardown, after the clock has stopped (openmp_task.c:188 takes the time before it frees anything) */
+    if (pats.n) for (int r = 0; r < n_cons; r++) kmpgpu_destroy(cons[r].total);
     kmp_batch_close(rd);
     for (int i = 0; i < sh.n_slots; i++) {
         kmpgpu_host_free(sh.slots[i].arena); kmpgpu_host_free(sh.slots[i].off); kmpgpu_host_free(sh.slots[i].len);

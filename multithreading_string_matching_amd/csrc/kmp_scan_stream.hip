@@ -184,7 +184,10 @@ kmp_build_bitmap_kernel(const uint64_t *__restrict__ pkt_off, uint64_t n, unsign
     }
 }
 
-/* plan[w] = first packet whose offset is >= off[0] + w * bytes_per_wave (w = 0..nwaves); plan[nwaves] = {n, end}. */
+/* plan[w] = the packet whose start lies CLOSEST to off[0] + w * bytes_per_wave (w = 0..nwaves); plan[nwaves] = {n, end}.
+ * Ranges are whole packets, so a range's length differs from bytes_per_wave by where packets happen to start; with the first start
+ * at or behind the target (round 2) that was up to one packet at either end -- 9000 bytes on ~41 KB ranges for the Zipf lengths of
+ * BASELINE configs[4], and a block is as slow as its slowest wavefront --, with the closest one it is half of that. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len, uint64_t n, uint64_t nwaves,
                 uint64_t bytes_per_wave, kmp_plan_entry *__restrict__ plan)
@@ -199,6 +202,11 @@ kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
         if (pkt_off[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    if (lo > 0 && w > 0) {
+        const uint64_t next = (lo < n) ? pkt_off[lo] : end;
+        /* (a target behind the arena's end -- more wavefronts than bytes_per_wave-sized pieces -- keeps lo = n: an empty range) */
+        if (next >= target && target - pkt_off[lo - 1] < next - target) --lo;      /* the start before the target is the closer one */
     }
     plan[w].k = lo;
     plan[w].off = (lo < n) ? pkt_off[lo] : end;

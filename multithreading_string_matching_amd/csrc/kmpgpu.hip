@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +94,7 @@ struct kmpgpu_ctx {
     bool            uniform = false;                  /* every payload has the same length, slots back to back */
     bool            packed = false;                   /* slots back to back (any lengths): flat streaming with bitmap + plan */
     bool            pad_clean = false;                /* packed arena whose slot padding is all 0x00 (kmp_check_padding_kernel) */
+    bool            pad_known_clean = false;          /* set around prepare_packed by a loader that wrote the padding itself: no check pass */
     uint64_t        span_end = 0;                     /* end offset of the last slot */
     unsigned long long *d_bitmap = nullptr;           /* one bit per 16-byte slot: a payload starts here */
     void           *d_plan = nullptr;                 /* kmp_plan_entry[plan_waves + 1] */
@@ -252,6 +254,40 @@ void release_arena(kmpgpu_ctx *c, bool keep_buffers = false)
     c->bitmap_live = false;                           /* the buffer itself (1/128 of an arena) is kept for the next arena */
 }
 
+/* Host ranges pinned through kmpgpu_host_register.  One copy must not straddle two registrations (the runtime refuses it), and a
+ * capture is pinned window by window: uploads are cut at the registrations' boundaries. */
+std::mutex g_pinned_mu;
+std::map<uintptr_t, size_t> g_pinned;
+
+hipError_t upload_split(void *dst, const uint8_t *src, uint64_t n, hipStream_t st)
+{
+    std::vector<std::pair<uint64_t, uint64_t>> pieces;          /* (offset, length) */
+    {
+        std::lock_guard<std::mutex> lock(g_pinned_mu);
+        if (g_pinned.empty()) pieces.emplace_back(0, n);
+        else {
+            uint64_t pos = 0;
+            while (pos < n) {
+                const uintptr_t a = (uintptr_t)src + pos;
+                uint64_t len = n - pos;
+                auto it = g_pinned.upper_bound(a);                /* first registration that starts behind a */
+                if (it != g_pinned.begin()) {
+                    auto in = std::prev(it);
+                    if (a < in->first + in->second) len = std::min<uint64_t>(len, in->first + in->second - a);       /* inside one: up to its end */
+                    else if (it != g_pinned.end()) len = std::min<uint64_t>(len, it->first - a);                     /* pageable stretch up to the next */
+                } else if (it != g_pinned.end()) len = std::min<uint64_t>(len, it->first - a);
+                pieces.emplace_back(pos, len);
+                pos += len;
+            }
+        }
+    }
+    for (const auto &p : pieces) {
+        const hipError_t e = hipMemcpyAsync((uint8_t *)dst + p.first, src + p.first, p.second, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 /* a device buffer of at least `want` elements, kept between calls: grown (with an eighth of headroom) only when it is too small */
 template <typename T>
 hipError_t grow_buffer(T **p, uint64_t *cap, uint64_t want)
@@ -331,6 +367,7 @@ int prepare_packed(kmpgpu_ctx *c)
     /* slot padding: checked once; cleared when the arena is the context's own copy, otherwise the packed
      * kernel keeps fetching offset and length of a candidate's payload from the index */
     const bool own = c->owned_arena && c->d_arena == (const uint8_t *)c->owned_arena;
+    if (own && c->pad_known_clean) { c->pad_clean = true; return KMPGPU_OK; }
     uint32_t dirty = 0;
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(kmp_launch_check_padding(const_cast<uint8_t *>(c->d_arena), c->d_off, c->d_len, c->n_pkts, own ? 1 : 0, c->d_err, c->stream));
@@ -583,6 +620,27 @@ void *kmpgpu_host_alloc(size_t bytes)
 
 void kmpgpu_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+int kmpgpu_host_register(const void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return fail(KMPGPU_EINVAL, "kmpgpu_host_register: NULL / empty range");
+    if ((uintptr_t)ptr & 4095u) return fail(KMPGPU_EINVAL, "kmpgpu_host_register: the range must start on a page boundary");
+    /* portable: visible to every device's context (several shards upload from one mapping); the memory may be a PROT_READ mapping */
+    hipError_t e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable | hipHostRegisterReadOnly);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable); }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(KMPGPU_EHIP, "hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> lock(g_pinned_mu);
+    g_pinned[(uintptr_t)ptr] = bytes;
+    return KMPGPU_OK;
+}
+
+int kmpgpu_host_unregister(const void *ptr)
+{
+    if (!ptr) return fail(KMPGPU_EINVAL, "kmpgpu_host_unregister: NULL");
+    { std::lock_guard<std::mutex> lock(g_pinned_mu); g_pinned.erase((uintptr_t)ptr); }
+    HIP_TRY(hipHostUnregister(const_cast<void *>(ptr)));
+    return KMPGPU_OK;
+}
+
 int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t *pat_len, uint32_t n_pat)
 {
     if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_set_patterns: ctx is NULL");
@@ -804,7 +862,7 @@ int kmpgpu_load_arena(kmpgpu_ctx *c, const uint8_t *arena, uint64_t arena_bytes,
         c->cap_arena = arena_bytes; c->cap_pkts = n_pkts;
     }
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->owned_arena, arena, arena_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(upload_split(c->owned_arena, arena, arena_bytes, c->stream));
     HIP_TRY(hipMemcpyAsync(c->owned_off, pkt_off, n_pkts * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->owned_len, pkt_len, n_pkts * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -875,18 +933,15 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     HIP_TRY(grow_buffer(&c->fr_ws, &c->fr_ws_cap, (uint64_t)kmp_extract_ws_bytes(n_frames)));
     if (!c->fr_tot) HIP_TRY(hipMalloc(&c->fr_tot, 2 * sizeof(unsigned long long)));
 
-    std::vector<uint64_t> rel;                          /* the frame offsets are uploaded relative to the span's first byte */
-    if (span_lo) {
-        rel.resize(n_frames);
-        for (uint64_t f = 0; f < n_frames; f++) rel[f] = frame_off[f] - span_lo;
-        frame_off = rel.data();
-    }
+    /* the device buffer holds the file's bytes [span_lo, span_hi): the kernels address it through the pointer that stands for
+     * the file's first byte, so the frame offsets go up as they are (no rebased copy of them on the host) */
+    const uint8_t *d_file0 = c->fr_file - span_lo;
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(hipMemcpyAsync(c->fr_file, file_bytes + span_lo, span, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(upload_split(c->fr_file, file_bytes + span_lo, span, c->stream));
     HIP_TRY(hipMemcpyAsync(c->fr_off, frame_off, n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->fr_cl, frame_caplen, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    HIP_TRY(kmp_launch_extract_phase1(c->fr_file, c->fr_off, c->fr_cl, n_frames, tcp, c->fr_ws, c->fr_tot, c->stream));
+    HIP_TRY(kmp_launch_extract_phase1(d_file0, c->fr_off, c->fr_cl, n_frames, tcp, c->fr_ws, c->fr_tot, c->stream));
     unsigned long long tot[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(tot, c->fr_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -910,17 +965,57 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     }
     HIP_TRY(grow_buffer(&c->fr_src, &c->fr_src_cap, n_pkts));
     HIP_TRY(hipMemsetAsync((uint8_t *)c->owned_arena + tot[0], 0, 64, c->stream));
-    HIP_TRY(kmp_launch_extract_phase2(c->fr_file, c->fr_off, n_frames, c->fr_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
+    HIP_TRY(kmp_launch_extract_phase2(d_file0, c->fr_off, n_frames, c->fr_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
                                       (uint32_t *)c->owned_len, c->fr_src, c->stream));
     c->d_arena = (const uint8_t *)c->owned_arena;
     c->d_off = (const uint64_t *)c->owned_off;
     c->d_len = (const uint32_t *)c->owned_len;
     c->arena_bytes = arena_bytes; c->n_pkts = n_pkts;
+    c->pad_known_clean = true;                          /* kmp_gather_kernel writes every slot whole: payload, then 0x00 up to the slot's end */
     const int rc = finish_device_index(c, "kmpgpu_load_frames");
+    c->pad_known_clean = false;
     /* one capture uploaded whole: its bytes are not kept around (a streamed capture's batches are small and the next one
      * reuses the buffer) */
     if (c->fr_file_cap > (1ull << 30)) { (void)hipFree(c->fr_file); c->fr_file = nullptr; c->fr_file_cap = 0; }
     return rc;
+}
+
+int kmpgpu_reserve(kmpgpu_ctx *c, uint64_t arena_bytes, uint64_t n_pkts, uint64_t frame_bytes, uint64_t n_frames)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_reserve: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (arena_bytes && n_pkts && !(c->owned_arena && c->cap_arena >= arena_bytes && c->cap_pkts >= n_pkts)) {
+        if (c->d_arena == (const uint8_t *)c->owned_arena) release_arena(c, true);        /* the arena in use lives in these buffers */
+        if (c->owned_arena) HIP_TRY(hipFree(c->owned_arena));
+        if (c->owned_off) HIP_TRY(hipFree(c->owned_off));
+        if (c->owned_len) HIP_TRY(hipFree(c->owned_len));
+        c->owned_arena = c->owned_off = c->owned_len = nullptr; c->cap_arena = c->cap_pkts = 0;
+        HIP_TRY(hipMalloc(&c->owned_arena, arena_bytes));
+        HIP_TRY(hipMalloc(&c->owned_off, n_pkts * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&c->owned_len, n_pkts * sizeof(uint32_t)));
+        c->cap_arena = arena_bytes; c->cap_pkts = n_pkts;
+    }
+    if (arena_bytes) {
+        const uint64_t words = arena_bytes / KMP_CHUNK + 32;
+        if (c->bitmap_cap < words) {
+            const bool live = c->bitmap_live;
+            if (live) return fail(KMPGPU_ESTATE, "kmpgpu_reserve: an arena larger than the reserved size is attached");
+            if (c->d_bitmap) HIP_TRY(hipFree(c->d_bitmap));
+            c->d_bitmap = nullptr; c->bitmap_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_bitmap, words * sizeof(unsigned long long)));
+            c->bitmap_cap = words;
+        }
+    }
+    if (frame_bytes && n_frames) {
+        HIP_TRY(grow_buffer(&c->fr_file, &c->fr_file_cap, frame_bytes + 64));
+        HIP_TRY(grow_buffer(&c->fr_off, &c->fr_off_cap, n_frames));
+        HIP_TRY(grow_buffer(&c->fr_cl, &c->fr_cl_cap, n_frames));
+        HIP_TRY(grow_buffer(&c->fr_ws, &c->fr_ws_cap, (uint64_t)kmp_extract_ws_bytes(n_frames)));
+        HIP_TRY(grow_buffer(&c->fr_src, &c->fr_src_cap, n_frames));
+        if (!c->fr_tot) HIP_TRY(hipMalloc(&c->fr_tot, 2 * sizeof(unsigned long long)));
+    }
+    return KMPGPU_OK;
 }
 
 int kmpgpu_attach_arena(kmpgpu_ctx *c, const void *d_arena, uint64_t arena_bytes, const void *d_pkt_off,

@@ -598,6 +598,44 @@ def test_nothing_behind_the_last_slot_is_read_or_counted(gm, oracle, L):
     del d_arena, d_off, d_len
 
 
+def test_upload_from_memory_pinned_in_windows(gm, oracle):
+    """kmpgpu_host_register: a caller may pin its buffer window by window; one upload that runs across several registrations
+    (and across a stretch that is not pinned at all) is cut at their boundaries -- the runtime refuses a copy that straddles
+    two of them."""
+    import ctypes as C
+    import mmap
+    G = _lib.gpu_lib()
+    page = mmap.PAGESIZE
+    rng = random.Random(5)
+    payloads = [bytes(rng.choice(b"abcd") for _ in range(rng.randrange(1, 3000))) for _ in range(600)]
+    a = K.HostArena.from_payloads(payloads)
+    n = int(a.bytes.size)
+    buf = mmap.mmap(-1, (n + 2 * page) // page * page)              # page-aligned, anonymous
+    view = np.frombuffer(buf, dtype=np.uint8)
+    view[:n] = a.bytes
+    base = view.ctypes.data
+    w = (n // 5) // page * page
+    assert w >= page
+    windows = [(0, w), (w, w), (3 * w, w)]                         # [2w, 3w) and the tail stay pageable
+    pats = [b"ab", b"abcd", b"dcba", b"a"]
+    want = oracle.count(a.bytes, a.off, a.len, pats)[0].tolist()
+    done = []
+    try:
+        for o, l in windows:
+            rc = G.kmpgpu_host_register(base + o, l)
+            if rc != 0:
+                pytest.skip("hipHostRegister refused: " + G.kmpgpu_last_error().decode())
+            done.append(o)
+        gm.set_patterns(pats)
+        gm.load_arena(view[:n], a.off, a.len)
+        assert gm.scan()[0].tolist() == want
+    finally:
+        for o in done:
+            assert G.kmpgpu_host_unregister(base + o) == 0
+        del view
+    assert G.kmpgpu_host_register(base + 1, 100) != 0               # not on a page boundary: refused, nothing registered
+
+
 def test_layout_contract_is_checked(gm):
     gm.set_patterns([b"http"])
     a = np.zeros(256, dtype=np.uint8)

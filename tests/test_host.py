@@ -252,6 +252,16 @@ def test_frame_batches_equal_the_frame_index(pcap, span, cap):
         assert o + c <= len(raw)
 
 
+def test_copy_bytes_is_memcpy():
+    L = _lib.host_lib()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 4095, (1 << 20) - 1, (1 << 20) + 17, 5 * (1 << 20) + 3):
+        src = rng.integers(0, 256, size=n + 8, dtype=np.uint8)
+        dst = np.full(n + 16, 0xEE, dtype=np.uint8)
+        L.kmp_copy_bytes(dst.ctypes.data + 8, src.ctypes.data + 3, n)
+        assert np.array_equal(dst[8:8 + n], src[3:3 + n]) and np.all(dst[:8] == 0xEE) and np.all(dst[8 + n:] == 0xEE)
+
+
 def test_arena_from_payloads_roundtrip():
     pls = [b"", b"x", b"hello world", b"a" * 16, b"b" * 17, b"", b"c" * 5000]
     a = K.HostArena.from_payloads(pls)

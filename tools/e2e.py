@@ -21,10 +21,13 @@ del host
 open(strings, "w").write("NEEDLE_16B_PATRN\n")
 planted = K.synth_count_planted(sp, n, L)
 runs = [("serial (host extraction)", ["serial", pcap, strings], {}),
-        ("serial, device extraction", ["serial", pcap, strings], {"KMPGPU_DEVICE_EXTRACT": "1"}),
-        ("openmp_task 1 (streamed batches)", ["openmp_task", pcap, strings, "1"], {}),
-        ("openmp_task 1, 256 MiB batches", ["openmp_task", pcap, strings, "1"], {"KMPGPU_BATCH_BYTES": str(256 << 20)})]
-for rep in range(2):                        # second round: file in the page cache for sure
+        ("openmp_task 1 (payload batches 64 MiB)", ["openmp_task", pcap, strings, "1"], {}),
+        ("openmp_task 1, raw frames 64 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1"}),
+        ("openmp_task 1, raw frames 16 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1", "KMPGPU_BATCH_BYTES": str(16 << 20)}),
+        ("openmp_task 1, raw frames 32 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1", "KMPGPU_BATCH_BYTES": str(32 << 20)}),
+        ("openmp_task 1, raw frames 128 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1", "KMPGPU_BATCH_BYTES": str(128 << 20)}),
+        ("openmp_task 2, raw frames 64 MiB", ["openmp_task", pcap, strings, "2"], {"KMPGPU_DEVICE_EXTRACT": "1"})]
+for rep in range(3):                        # second round: file in the page cache for sure
     for name, argv, env in runs:
         t = time.time()
         r = subprocess.run([os.path.join(_lib.BINDIR, argv[0])] + argv[1:], capture_output=True, text=True, env=dict(os.environ, KMPGPU_STATS="1", **env), timeout=600)
@@ -32,5 +35,5 @@ for rep in range(2):                        # second round: file in the page cac
         assert r.returncode == 0, r.stderr
         assert f"NEEDLE_16B_PATRN: {planted} times!" in r.stdout, r.stdout
         el = [l for l in r.stdout.splitlines() if l.startswith("Elapsed")][0]
-        print(f"[{rep}] {name:34s}: wall {wall:6.2f} s ({n*L/wall/1e9:5.2f} GB/s of payload)  {el}  | " + " | ".join(l for l in r.stderr.splitlines() if "kernel" in l or "streamed" in l or "phases" in l), flush=True)
+        print(f"[{rep}] {name:34s}: wall {wall:6.2f} s ({n*L/wall/1e9:5.2f} GB/s of payload)  {el}  | " + " | ".join(l.replace("[kmpgpu] ", "") for l in r.stderr.splitlines() if "kernel" in l or "streamed" in l or "phases" in l), flush=True)
 os.remove(pcap)

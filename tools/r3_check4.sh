@@ -1,0 +1,10 @@
+#!/bin/bash
+# round-3 check 4 (GPU box): end-to-end of the streamed programs with phase times; PMC passes of the fused pass on three shapes
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r3 gpurun_out/prof
+python tools/e2e.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3/e2e3.log
+for shape in 1500 zipf 64; do
+  KMP_SHAPE=$shape PMC_PROG="tools/run_fused.py" PMC_KERNEL=kmp_scan_multi bash tools/pmc.sh fused_r3_$shape > gpurun_out/r3/pmc_fused_$shape.log 2>&1; echo "pmc fused $shape rc=$?"
+  grep -h "^shape" gpurun_out/prof/pmc_fused_r3_$shape/p1.log >> gpurun_out/r3/pmc_fused_$shape.log
+done
+grep -E "SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS|SQ_BUSY_CYCLES|SQ_WAVES|^shape|FETCH_SIZE|SQ_LDS_BANK|SQ_INSTS_BRANCH|SQ_INSTS_SMEM" gpurun_out/r3/pmc_fused_*.log
