@@ -122,6 +122,8 @@ struct kmpgpu_ctx {
     unsigned long long *d_sum = nullptr;              /* [6] payload bytes, offset 0, stride, length 0, end of last slot */
     uint64_t           *h_counts = nullptr;           /* pinned */
     size_t              h_counts_cap = 0;
+    unsigned long long *h_small = nullptr;            /* pinned, 16 words: where the loaders read small device results back (a copy to pageable
+                                                         memory goes through the runtime's blocking staging path) */
 
     /* options */
     int mode = 0, blocks_per_cu = 0 /* auto */, depth = 0 /* auto */, nontemporal = 1, kernel_sel = 0, fused = 2 /* auto */, accumulate = 0, repack = 1;
@@ -371,8 +373,9 @@ int prepare_packed(kmpgpu_ctx *c)
     uint32_t dirty = 0;
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(kmp_launch_check_padding(const_cast<uint8_t *>(c->d_arena), c->d_off, c->d_len, c->n_pkts, own ? 1 : 0, c->d_err, c->stream));
-    HIP_TRY(hipMemcpyAsync(&dirty, c->d_err, sizeof dirty, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_small, c->d_err, sizeof dirty, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(&dirty, c->h_small, sizeof dirty);
     c->pad_clean = own || dirty == 0;
     return KMPGPU_OK;
 }
@@ -538,6 +541,7 @@ int kmpgpu_init(kmpgpu_ctx **out, int device)
     }
     if (e == hipSuccess) e = hipMalloc(&c->d_err, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_sum, 6 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_small, 16 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) {
         kmpgpu_destroy(c);
         return fail(KMPGPU_EHIP, "kmpgpu_init: %s", hipGetErrorString(e));
@@ -565,6 +569,7 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_sum) (void)hipFree(c->d_sum);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto ev : c->prof_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -890,9 +895,11 @@ static int finish_device_index(kmpgpu_ctx *c, const char *who)
     HIP_TRY(kmp_launch_validate(c->d_off, c->d_len, c->n_pkts, c->arena_bytes, c->d_err, c->d_sum, c->stream));
     uint32_t err[2] = {0, 0};
     unsigned long long info[6] = {0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(info, c->d_sum, sizeof info, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_small, c->d_sum, sizeof info, hipMemcpyDeviceToHost, c->stream));          /* (pinned: no staging) */
+    HIP_TRY(hipMemcpyAsync(c->h_small + 8, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(info, c->h_small, sizeof info);
+    memcpy(err, c->h_small + 8, sizeof err);
     if (err[0]) return fail(KMPGPU_EINVAL, "%s: the payload index violates the layout contract (flags %u)", who, err[0]);
     c->payload_bytes = info[0];
     c->uniform = ((err[1] & 1u) == 0) && info[2] >= 16 && info[2] < (1ull << 31);
@@ -943,8 +950,9 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     HIP_TRY(kmp_launch_extract_phase1(d_file0, c->fr_off, c->fr_cl, n_frames, tcp, c->fr_ws, c->fr_tot, c->stream));
     unsigned long long tot[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(tot, c->fr_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_small, c->fr_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));         /* (pinned: no staging) */
     HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(tot, c->h_small, sizeof tot);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->last.h2d_ms = ms;
@@ -1014,7 +1022,10 @@ int kmpgpu_reserve(kmpgpu_ctx *c, uint64_t arena_bytes, uint64_t n_pkts, uint64_
         HIP_TRY(grow_buffer(&c->fr_ws, &c->fr_ws_cap, (uint64_t)kmp_extract_ws_bytes(n_frames)));
         HIP_TRY(grow_buffer(&c->fr_src, &c->fr_src_cap, n_frames));
         if (!c->fr_tot) HIP_TRY(hipMalloc(&c->fr_tot, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->fr_file, 0, frame_bytes + 64, c->stream));      /* first touch now: the first upload into fresh device memory runs at 3/4 of the rate */
     }
+    if (c->owned_arena && arena_bytes && c->d_arena != (const uint8_t *)c->owned_arena) HIP_TRY(hipMemsetAsync(c->owned_arena, 0, std::min<uint64_t>(arena_bytes, c->cap_arena), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return KMPGPU_OK;
 }
 
