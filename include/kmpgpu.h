@@ -143,6 +143,15 @@ int  kmpgpu_load_arena(kmpgpu_ctx *ctx, const uint8_t *arena, uint64_t arena_byt
 int  kmpgpu_load_frames(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
                         const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads);
 
+/* The same in two steps, for a caller that keeps the copy engine busy (bin/openmp_task): _begin waits for the context's earlier passes,
+ * then ENQUEUES the upload and the first extraction stage on the context's stream and returns; _finish waits for them, packs the
+ * payloads and makes the new arena the context's current one.  Between the two the caller may begin a load on another context (its
+ * upload queues up behind this one) or finish an earlier one.  The host buffers handed to _begin must stay valid and unchanged until
+ * _finish has returned; scans of this context are only allowed again after _finish. */
+int  kmpgpu_load_frames_begin(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
+                              const uint32_t *frame_caplen, uint64_t n_frames, int tcp);
+int  kmpgpu_load_frames_finish(kmpgpu_ctx *ctx, uint64_t *n_payloads);
+
 /* Size the context's device buffers ahead of time for arenas of up to arena_bytes / n_pkts payloads and, when frame_bytes != 0, for
  * kmpgpu_load_frames calls of up to frame_bytes of capture / n_frames frames: a streamed capture (openmp_task.c:126-186) loads batch
  * after batch into the same buffers, and the first batch should not pay for a dozen device allocations.  Optional: every loader

@@ -30,7 +30,6 @@
 #include "kmpgpu.h"
 #include "kmphost.h"
 
-#define SLOTS_PER_SHARD 5               /* one being walked / read, one being staged, two being uploaded, one spare */
 
 typedef struct slot {
     uint8_t  *arena;                 /* pinned: the payload arena of a batch / the raw bytes of a frame batch */
@@ -61,12 +60,14 @@ typedef struct shared {
     const uint8_t  *file;
     uint64_t        file_bytes;
     uint64_t        batch_bytes, cap_pkts;
+    int             per_shard;       /* consumer threads (contexts) per GPU shard */
 } shared;
 
 typedef struct consumer {
     shared   *sh;
     int       id;
-    kmpgpu_ctx *total;               /* the context that holds this shard's counts when the consumer is done */
+    kmpgpu_ctx *total;               /* the context that holds this consumer's counts when it is done */
+    kmpgpu_ctx *extra;               /* raw frames: its second context */
     double    kernel_ms, h2d_ms;
     uint64_t  batches, payloads, bytes;
     double    load_s, wait_s;        /* time inside the load calls / waiting for a filled slot */
@@ -114,56 +115,105 @@ static void *stage_batches(void *arg)
     }
 }
 
-static void *consume(void *arg)
+static kmpgpu_ctx *make_context(const shared *sh, int device)
 {
-    consumer *me = (consumer *)arg;
-    shared *sh = me->sh;
-    /* one context (own stream, own device buffers) per consumer thread, TWO threads per GPU shard: while one of them is inside a load
-     * call -- upload, extraction, the few synchronisations in between --, the other one's upload is already under way, and the scans
-     * run behind both (round 2 alternated two contexts from ONE thread: the copy engine idled whenever that thread waited) */
     kmpgpu_ctx *c = NULL;
-    if (kmpgpu_init(&c, (me->id / 2) % sh->ndev)) die_gpu("kmpgpu_init");
+    if (kmpgpu_init(&c, device)) die_gpu("kmpgpu_init");
     if (kmpgpu_set_patterns(c, sh->pp, sh->pats->len, sh->pats->n)) die_gpu("kmpgpu_set_patterns");
     if (kmpgpu_set_option(c, KMPGPU_OPT_ACCUMULATE, 1) || kmpgpu_counts_reset(c)) die_gpu("kmpgpu_set_option");
     /* the device buffers of a batch, once: the first batch does not pay for a dozen allocations under the clock */
     if (kmpgpu_reserve(c, sh->batch_bytes + 64, sh->cap_pkts, sh->frames_mode ? sh->batch_bytes + 64 : 0, sh->frames_mode ? sh->cap_pkts : 0)) die_gpu("kmpgpu_reserve");
     if (kmpgpu_sync(c)) die_gpu("kmpgpu_sync");
-    me->total = c;
-    pthread_mutex_lock(&sh->mu);                               /* the context is up: the clock may start (main waits for every consumer) */
+    return c;
+}
+
+/* the next filled slot, or NULL when the capture is through */
+static slot *take_slot(consumer *me)
+{
+    shared *sh = me->sh;
+    const double tw0 = now_s();
+    pthread_mutex_lock(&sh->mu);
+    while (sh->next_take == sh->next_fill && !sh->done) pthread_cond_wait(&sh->cv, &sh->mu);
+    me->wait_s += now_s() - tw0;
+    slot *s = NULL;
+    if (sh->next_take != sh->next_fill) { s = &sh->slots[sh->next_take % (uint64_t)sh->n_slots]; sh->next_take++; }
+    pthread_mutex_unlock(&sh->mu);
+    return s;
+}
+
+static void free_slot(shared *sh, slot *s)
+{
+    pthread_mutex_lock(&sh->mu);
+    s->state = 0;                                            /* the pinned buffer may be refilled */
+    pthread_cond_broadcast(&sh->cv);
+    pthread_mutex_unlock(&sh->mu);
+}
+
+static void *consume(void *arg)
+{
+    consumer *me = (consumer *)arg;
+    shared *sh = me->sh;
+    const int device = (me->id / sh->per_shard) % sh->ndev;
+    /* Contexts have their own stream and device buffers.  Payload batches: one context per consumer thread, two threads per shard
+     * (the upload of one overlaps the scan of the other).  Raw frames: ONE thread per shard drives TWO contexts and keeps the copy
+     * engine fed -- the upload of batch i + 1 is enqueued (kmpgpu_load_frames_begin) before the thread waits for batch i's
+     * extraction (kmpgpu_load_frames_finish), so the uploads follow each other without a gap and the extraction and the scans
+     * run behind them. */
+    kmpgpu_ctx *ctx[2] = {make_context(sh, device), sh->frames_mode ? make_context(sh, device) : NULL};
+    me->total = ctx[0]; me->extra = ctx[1];
+    pthread_mutex_lock(&sh->mu);                               /* the contexts are up: the clock may start (main waits for every consumer) */
     sh->ready++;
     pthread_cond_broadcast(&sh->cv);
     pthread_mutex_unlock(&sh->mu);
-    for (;;) {
-        const double tw0 = now_s();
-        pthread_mutex_lock(&sh->mu);
-        while (sh->next_take == sh->next_fill && !sh->done) pthread_cond_wait(&sh->cv, &sh->mu);
-        me->wait_s += now_s() - tw0;
-        if (sh->next_take == sh->next_fill && sh->done) { pthread_mutex_unlock(&sh->mu); break; }
-        slot *s = &sh->slots[sh->next_take % (uint64_t)sh->n_slots];
-        sh->next_take++;
-        pthread_mutex_unlock(&sh->mu);
 
-        /* waits for this context's previous scan, uploads (the other contexts' work keeps running) */
-        const double tl0 = now_s();
-        if (sh->frames_mode) {
-            uint64_t np = 0, pb = 0;
-            if (kmpgpu_load_frames(c, s->arena, s->used, s->off, s->len, s->n, sh->tcp, &np)) die_gpu("kmpgpu_load_frames");
-            kmpgpu_arena_info(c, NULL, &pb);
-            me->payloads += np; me->bytes += np ? pb : 0;
-        } else {
+    if (sh->frames_mode) {
+        slot *pend[2] = {NULL, NULL};
+        int turn = 0;
+        for (;;) {
+            slot *s = take_slot(me);
+            const double tl0 = now_s();
+            if (s) {
+                if (kmpgpu_load_frames_begin(ctx[turn], s->arena, s->used, s->off, s->len, s->n, sh->tcp)) die_gpu("kmpgpu_load_frames");
+                pend[turn] = s;
+            }
+            /* then the batch begun before this one (the other context); at the end of the capture, whatever is still pending */
+            const int order[2] = {turn ^ 1, turn};
+            for (int i = 0; i < (s ? 1 : 2); i++) {
+                const int k = order[i];
+                if (!pend[k]) continue;
+                uint64_t np = 0, pb = 0;
+                if (kmpgpu_load_frames_finish(ctx[k], &np)) die_gpu("kmpgpu_load_frames");
+                kmpgpu_arena_info(ctx[k], NULL, &pb);
+                me->payloads += np; me->bytes += np ? pb : 0;
+                { kmpgpu_timing tt; if (kmpgpu_last_timing(ctx[k], &tt) == 0) me->h2d_ms += tt.h2d_ms; }
+                me->batches++;
+                free_slot(sh, pend[k]);
+                pend[k] = NULL;
+                if (kmpgpu_scan_enqueue(ctx[k], NULL)) die_gpu("kmpgpu_scan_enqueue");
+            }
+            me->load_s += now_s() - tl0;
+            if (!s) break;
+            turn ^= 1;
+        }
+        /* the two contexts' running totals are merged on the device (openmp_task.c:172-175) */
+        if (kmpgpu_counts_add(ctx[0], ctx[1])) die_gpu("kmpgpu_counts_add");
+    } else {
+        kmpgpu_ctx *c = ctx[0];
+        for (;;) {
+            slot *s = take_slot(me);
+            if (!s) break;
+            /* waits for this context's previous scan, uploads (the other contexts' work keeps running) */
+            const double tl0 = now_s();
             if (kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n)) die_gpu("kmpgpu_load_arena");
             me->payloads += s->n;
+            me->load_s += now_s() - tl0;
+            { kmpgpu_timing tt; if (kmpgpu_last_timing(c, &tt) == 0) me->h2d_ms += tt.h2d_ms; }
+            me->batches++;
+            free_slot(sh, s);
+            if (kmpgpu_scan_enqueue(c, NULL)) die_gpu("kmpgpu_scan_enqueue");
         }
-        me->load_s += now_s() - tl0;
-        { kmpgpu_timing tt; if (kmpgpu_last_timing(c, &tt) == 0) me->h2d_ms += tt.h2d_ms; }
-        me->batches++;
-        pthread_mutex_lock(&sh->mu);
-        s->state = 0;                                        /* the pinned buffer may be refilled */
-        pthread_cond_broadcast(&sh->cv);
-        pthread_mutex_unlock(&sh->mu);
-        if (kmpgpu_scan_enqueue(c, NULL)) die_gpu("kmpgpu_scan_enqueue");
     }
-    if (kmpgpu_sync(c)) die_gpu("kmpgpu_sync");
+    if (kmpgpu_sync(ctx[0])) die_gpu("kmpgpu_sync");
     return NULL;
 }
 
@@ -207,15 +257,20 @@ int main(int argc, char *argv[])
     /* a frame record takes 16 bytes of header and up; a payload slot 16 bytes and up, 64 on average or more in practice */
     const uint64_t cap_pkts = frames_mode ? batch_bytes / 32 : batch_bytes / 64;
 
+    /* consumer threads (contexts) per GPU shard: two by default; KMPGPU_STREAM_CONTEXTS = 1..8 */
+    int per_shard = 2;
+    { const char *e = getenv("KMPGPU_STREAM_CONTEXTS"); if (e && atoi(e) >= 1 && atoi(e) <= 8) per_shard = atoi(e); }
+    { const char *dx0 = getenv("KMPGPU_DEVICE_EXTRACT"); if (dx0 && dx0[0] == '1') per_shard = 1; }       /* raw frames: one thread per shard drives two contexts */
     shared sh;
     memset(&sh, 0, sizeof sh);
     pthread_mutex_init(&sh.mu, NULL);
     pthread_cond_init(&sh.cv, NULL);
-    sh.n_slots = SLOTS_PER_SHARD * shards;
+    /* one being walked / read, one being staged, one or two per consumer being uploaded, one spare */
+    sh.n_slots = (frames_mode ? 5 : 3 + per_shard) * shards;
     sh.slots = (slot *)calloc((size_t)sh.n_slots, sizeof(slot));
     sh.pats = &pats; sh.ndev = ndev;
     sh.frames_mode = frames_mode; sh.tcp = proto == KMP_PROTO_TCP;
-    sh.batch_bytes = batch_bytes; sh.cap_pkts = cap_pkts;
+    sh.batch_bytes = batch_bytes; sh.cap_pkts = cap_pkts; sh.per_shard = per_shard;
     sh.file = kmp_batch_file(rd, &sh.file_bytes);
     sh.pp = (const uint8_t **)malloc(sizeof(uint8_t *) * (pats.n ? pats.n : 1));
     for (uint32_t i = 0; i < pats.n; i++) sh.pp[i] = pats.blob + pats.off[i];
@@ -228,7 +283,7 @@ int main(int argc, char *argv[])
 
     /* The consumers and their GPU contexts (streams, pattern tables) are set up before the clock starts, like the pinned
      * buffers above and like everything openmp_task.c does before :124 (pattern load, pcap_open_offline, allocations). */
-    const int n_cons = 2 * shards;                                                                  /* two consumer threads (contexts) per GPU shard */
+    const int n_cons = per_shard * shards;
     consumer *cons = (consumer *)calloc((size_t)n_cons, sizeof(consumer));
     pthread_t *th = (pthread_t *)calloc((size_t)n_cons, sizeof(pthread_t));
     if (pats.n) {
@@ -301,11 +356,12 @@ int main(int argc, char *argv[])
             if (frames_mode) { payloads += cons[r].payloads; bytes += cons[r].bytes; }              /* what the GPUs extracted */
         }
         for (int r = 0; r < shards; r++) {
-            /* a shard's two contexts' running totals are merged on the device (openmp_task.c:172-175); the shard's counters stay
+            /* a shard's contexts' running totals are merged on the device (openmp_task.c:172-175); the shard's counters stay
              * there for the reduce over the shards */
-            if (kmpgpu_counts_add(cons[2 * r].total, cons[2 * r + 1].total)) die_gpu("kmpgpu_counts_add");
-            if (kmpgpu_sync(cons[2 * r].total)) die_gpu("kmpgpu_sync");
-            tot[r] = cons[2 * r].total;
+            for (int k = 1; k < per_shard; k++)
+                if (kmpgpu_counts_add(cons[per_shard * r].total, cons[per_shard * r + k].total)) die_gpu("kmpgpu_counts_add");
+            if (kmpgpu_sync(cons[per_shard * r].total)) die_gpu("kmpgpu_sync");
+            tot[r] = cons[per_shard * r].total;
         }
         /* The sum over the shards (mpi_dumping.c:202): one shard per device -> RCCL all-reduce of the device counters and
          * one download; shards that share a device -> host sum.  KMPGPU_RCCL=0 / 1 as in bin/openmp_data. */
@@ -344,13 +400,13 @@ int main(int argc, char *argv[])
     { const char *st = getenv("KMPGPU_STATS");
       if (st && st[0] && st[0] != '0') {
           double load_s = 0, wait_s = 0, h2d = 0;
-          for (int r = 0; r < 2 * shards; r++) { load_s += cons[r].load_s; wait_s += cons[r].wait_s; h2d += cons[r].h2d_ms; }
+          for (int r = 0; r < (pats.n ? n_cons : 0); r++) { load_s += cons[r].load_s; wait_s += cons[r].wait_s; h2d += cons[r].h2d_ms; }
           fprintf(stderr, "[kmpgpu] phases: producer %.3f s building batches + %.3f s waiting for a free slot; staging copies %.3f s; consumers %.3f s in the load calls "
                           "(uploads by the events: %.3f s), %.3f s waiting for a batch\n",
                   prod_walk_s, prod_wait_s, sh.copy_s, load_s, h2d * 1e-3, wait_s);
       } }
     /* teardown, after the clock has stopped (openmp_task.c:188 takes the time before it frees anything) */
-    if (pats.n) for (int r = 0; r < n_cons; r++) kmpgpu_destroy(cons[r].total);
+    if (pats.n) for (int r = 0; r < n_cons; r++) { kmpgpu_destroy(cons[r].total); if (cons[r].extra) kmpgpu_destroy(cons[r].extra); }
     kmp_batch_close(rd);
     for (int i = 0; i < sh.n_slots; i++) {
         kmpgpu_host_free(sh.slots[i].arena); kmpgpu_host_free(sh.slots[i].off); kmpgpu_host_free(sh.slots[i].len);

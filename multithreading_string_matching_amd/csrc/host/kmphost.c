@@ -7,6 +7,9 @@
 #include "kmphost.h"
 
 #include <errno.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -721,6 +724,29 @@ const uint8_t *kmp_batch_file(const kmp_batch_reader *r, uint64_t *nbytes)
     return r ? r->view.base : NULL;
 }
 
+/* One piece of kmp_copy_bytes.  The destination is a pinned staging buffer that the GPU's copy engine reads next and the CPU never
+ * reads again: streaming (non-temporal) stores write it past the caches -- no read-for-ownership of the destination lines, and the
+ * DMA that follows finds the bytes in DRAM instead of probing dirty lines out of sixteen cores' caches. */
+static void copy_streaming(uint8_t *dst, const uint8_t *src, uint64_t n)
+{
+#if defined(__SSE2__)
+    uint64_t head = (16u - ((uintptr_t)dst & 15u)) & 15u;
+    if (head > n) head = n;
+    if (head) { memcpy(dst, src, (size_t)head); dst += head; src += head; n -= head; }
+    const uint64_t body = n & ~(uint64_t)63;
+    for (uint64_t o = 0; o < body; o += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(src + o)), b = _mm_loadu_si128((const __m128i *)(src + o + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i *)(src + o + 32)), d = _mm_loadu_si128((const __m128i *)(src + o + 48));
+        _mm_stream_si128((__m128i *)(dst + o), a); _mm_stream_si128((__m128i *)(dst + o + 16), b);
+        _mm_stream_si128((__m128i *)(dst + o + 32), c); _mm_stream_si128((__m128i *)(dst + o + 48), d);
+    }
+    if (n > body) memcpy(dst + body, src + body, (size_t)(n - body));
+    _mm_sfence();
+#else
+    memcpy(dst, src, (size_t)n);
+#endif
+}
+
 void kmp_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
 {
     const uint64_t piece = 1u << 20;
@@ -730,7 +756,7 @@ void kmp_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
 #pragma omp parallel for num_threads(nt) schedule(static)
     for (int64_t i = 0; i < pieces; i++) {
         const uint64_t o = (uint64_t)i * piece, l = (n - o < piece) ? n - o : piece;
-        memcpy(dst + o, src + o, (size_t)l);
+        copy_streaming(dst + o, src + o, l);
     }
 }
 

@@ -112,6 +112,9 @@ struct kmpgpu_ctx {
     uint64_t       *fr_off = nullptr, *fr_src = nullptr;
     uint32_t       *fr_cl = nullptr;
     unsigned long long *fr_tot = nullptr;
+    bool            fr_pending = false;               /* kmpgpu_load_frames_begin has enqueued an upload that kmpgpu_load_frames_finish has not taken yet */
+    uint64_t        fr_n = 0, fr_span = 0, fr_span_lo = 0;
+    int             fr_tcp = 0;
     uint64_t        fr_file_cap = 0, fr_off_cap = 0, fr_cl_cap = 0, fr_ws_cap = 0, fr_src_cap = 0;
 
     /* results */
@@ -909,11 +912,12 @@ static int finish_device_index(kmpgpu_ctx *c, const char *who)
     return prepare_packed(c);
 }
 
-int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
-                       const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads)
+int kmpgpu_load_frames_begin(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
+                             const uint32_t *frame_caplen, uint64_t n_frames, int tcp)
 {
     if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: ctx is NULL");
     if (n_frames && (!file_bytes || !frame_off || !frame_caplen)) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: NULL buffers");
+    if (c->fr_pending) return fail(KMPGPU_ESTATE, "kmpgpu_load_frames_begin: the previous load has not been finished");
     /* Only the bytes these frames span are uploaded: a shard of the frames (mpi_dumping.c:149-161 scatters shares, not
      * the whole capture) or a batch of a streamed capture (openmp_task.c:126-155) costs its share of PCIe time and HBM. */
     uint64_t span_lo = file_nbytes, span_hi = 0;
@@ -927,10 +931,10 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     span_lo &= ~(uint64_t)15;                           /* keeps the frames' alignment relative to the device buffer */
     const uint64_t span = span_hi - span_lo;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));           /* the passes over the arena that is about to be replaced */
     release_arena(c, /* keep_buffers = */ true);        /* batch after batch: device buffers are reused when the next batch fits */
     c->last.h2d_ms = 0; c->last.h2d_bytes = 0;
-    if (n_payloads) *n_payloads = 0;
+    c->fr_pending = true; c->fr_n = n_frames; c->fr_tcp = tcp; c->fr_span = span; c->fr_span_lo = span_lo;
     if (n_frames == 0) return KMPGPU_OK;
 
     /* scratch, grown on demand and kept (no hipMalloc / hipFree per batch: either synchronises the whole device) */
@@ -949,9 +953,21 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
     HIP_TRY(hipMemcpyAsync(c->fr_cl, frame_caplen, n_frames * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     HIP_TRY(kmp_launch_extract_phase1(d_file0, c->fr_off, c->fr_cl, n_frames, tcp, c->fr_ws, c->fr_tot, c->stream));
-    unsigned long long tot[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(c->h_small, c->fr_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));         /* (pinned: no staging) */
+    HIP_TRY(hipMemcpyAsync(c->h_small, c->fr_tot, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));         /* (pinned: no staging) */
+    return KMPGPU_OK;
+}
+
+int kmpgpu_load_frames_finish(kmpgpu_ctx *c, uint64_t *n_payloads)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: ctx is NULL");
+    if (n_payloads) *n_payloads = 0;
+    if (!c->fr_pending) return fail(KMPGPU_ESTATE, "kmpgpu_load_frames_finish: no load has been begun");
+    c->fr_pending = false;
+    const uint64_t n_frames = c->fr_n, span = c->fr_span;
+    if (n_frames == 0) return KMPGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long tot[2] = {0, 0};
     memcpy(tot, c->h_small, sizeof tot);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
@@ -972,6 +988,7 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
         c->cap_arena = take_b; c->cap_pkts = take_n;
     }
     HIP_TRY(grow_buffer(&c->fr_src, &c->fr_src_cap, n_pkts));
+    const uint8_t *d_file0 = c->fr_file - c->fr_span_lo;
     HIP_TRY(hipMemsetAsync((uint8_t *)c->owned_arena + tot[0], 0, 64, c->stream));
     HIP_TRY(kmp_launch_extract_phase2(d_file0, c->fr_off, n_frames, c->fr_ws, n_pkts, (uint8_t *)c->owned_arena, (uint64_t *)c->owned_off,
                                       (uint32_t *)c->owned_len, c->fr_src, c->stream));
@@ -986,6 +1003,14 @@ int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_n
      * reuses the buffer) */
     if (c->fr_file_cap > (1ull << 30)) { (void)hipFree(c->fr_file); c->fr_file = nullptr; c->fr_file_cap = 0; }
     return rc;
+}
+
+int kmpgpu_load_frames(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
+                       const uint32_t *frame_caplen, uint64_t n_frames, int tcp, uint64_t *n_payloads)
+{
+    if (n_payloads) *n_payloads = 0;
+    const int rc = kmpgpu_load_frames_begin(c, file_bytes, file_nbytes, frame_off, frame_caplen, n_frames, tcp);
+    return rc ? rc : kmpgpu_load_frames_finish(c, n_payloads);
 }
 
 int kmpgpu_reserve(kmpgpu_ctx *c, uint64_t arena_bytes, uint64_t n_pkts, uint64_t frame_bytes, uint64_t n_frames)
