@@ -11,6 +11,7 @@
 #include <emmintrin.h>
 #endif
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -127,6 +128,28 @@ static int host_threads(void)
     if (n < 1) n = 1;
     cached = n;
     return n;
+}
+
+/* Fork-join over [0, n) with plain threads that exist for the call only.  The copy loops of a streamed capture run between
+ * GPU uploads; an OpenMP team would keep spinning on its cores after every loop (libgomp's wait policy, fixed when the library
+ * is loaded), and on a host that grants this process a CPU quota those spinning threads are taken out of the share of the
+ * threads that feed the GPU. */
+typedef void (*kmp_range_fn)(void *arg, int64_t lo, int64_t hi);
+typedef struct kmp_range_job { kmp_range_fn fn; void *arg; int64_t lo, hi; } kmp_range_job;
+static void *range_thread(void *p) { kmp_range_job *j = (kmp_range_job *)p; j->fn(j->arg, j->lo, j->hi); return NULL; }
+static void run_parallel(int64_t n, int nthreads, kmp_range_fn fn, void *arg)
+{
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads < 1 || n < 2 * nthreads) nthreads = 1;
+    kmp_range_job job[64];
+    pthread_t th[64];
+    int started[64];
+    for (int t = 0; t < nthreads; t++) {
+        job[t].fn = fn; job[t].arg = arg; job[t].lo = n * t / nthreads; job[t].hi = n * (t + 1) / nthreads;
+        started[t] = t > 0 && pthread_create(&th[t], NULL, range_thread, &job[t]) == 0;
+    }
+    for (int t = 0; t < nthreads; t++) if (!started[t]) fn(arg, job[t].lo, job[t].hi);      /* thread 0, and whatever could not be started */
+    for (int t = 1; t < nthreads; t++) if (started[t]) pthread_join(th[t], NULL);
 }
 
 #define PCAPNG_SHB 0x0A0D0D0Au
@@ -652,6 +675,18 @@ kmp_batch_reader *kmp_batch_open(const char *path, int proto, char errbuf[KMP_PC
     return r;
 }
 
+typedef struct batch_copy_job { uint8_t *arena; const uint8_t *file; const uint64_t *src, *off; const uint32_t *len; } batch_copy_job;
+static void batch_copy_range(void *arg, int64_t lo, int64_t hi)
+{
+    const batch_copy_job *j = (const batch_copy_job *)arg;
+    for (int64_t k = lo; k < hi; k++) {
+        const uint64_t slot = round_up(j->len[k] ? j->len[k] : 1, KMP_SLOT_ALIGN);
+        uint8_t *d = j->arena + j->off[k];
+        if (j->len[k]) memcpy(d, j->file + j->src[k], j->len[k]);
+        if (slot > j->len[k]) memset(d + j->len[k], 0, (size_t)(slot - j->len[k]));
+    }
+}
+
 int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, uint64_t *off, uint32_t *len,
                        uint64_t cap_pkts, uint64_t *used_bytes, uint64_t *frames)
 {
@@ -685,15 +720,8 @@ int64_t kmp_batch_next(kmp_batch_reader *r, uint8_t *arena, uint64_t cap_bytes, 
         r->pending = 0;
     }
     /* 2: copy the payloads, several threads (the arena is usually pinned memory) */
-    const int nt = host_threads();
-    (void)nt;
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (int64_t k = 0; k < (int64_t)n; k++) {
-        const uint64_t slot = round_up(len[k] ? len[k] : 1, KMP_SLOT_ALIGN);
-        uint8_t *d = arena + off[k];
-        if (len[k]) memcpy(d, r->view.base + r->src[k], len[k]);
-        if (slot > len[k]) memset(d + len[k], 0, (size_t)(slot - len[k]));
-    }
+    batch_copy_job bj = {arena, r->view.base, r->src, off, len};
+    run_parallel((int64_t)n, host_threads(), batch_copy_range, &bj);
     if (n) memset(arena + pos, 0, KMP_ARENA_SLACK);
     if (used_bytes) *used_bytes = n ? pos + KMP_ARENA_SLACK : 0;
     return (int64_t)n;
@@ -747,17 +775,21 @@ static void copy_streaming(uint8_t *dst, const uint8_t *src, uint64_t n)
 #endif
 }
 
+typedef struct bytes_copy_job { uint8_t *dst; const uint8_t *src; uint64_t n, piece; } bytes_copy_job;
+static void bytes_copy_range(void *arg, int64_t lo, int64_t hi)
+{
+    const bytes_copy_job *j = (const bytes_copy_job *)arg;
+    for (int64_t i = lo; i < hi; i++) {
+        const uint64_t o = (uint64_t)i * j->piece, l = (j->n - o < j->piece) ? j->n - o : j->piece;
+        copy_streaming(j->dst + o, j->src + o, l);
+    }
+}
+
 void kmp_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n)
 {
     const uint64_t piece = 1u << 20;
-    const int64_t pieces = (int64_t)((n + piece - 1) / piece);
-    const int nt = host_threads();
-    (void)nt;
-#pragma omp parallel for num_threads(nt) schedule(static)
-    for (int64_t i = 0; i < pieces; i++) {
-        const uint64_t o = (uint64_t)i * piece, l = (n - o < piece) ? n - o : piece;
-        copy_streaming(dst + o, src + o, l);
-    }
+    bytes_copy_job bj = {dst, src, n, piece};
+    run_parallel((int64_t)((n + piece - 1) / piece), host_threads(), bytes_copy_range, &bj);
 }
 
 void kmp_batch_close(kmp_batch_reader *r)
