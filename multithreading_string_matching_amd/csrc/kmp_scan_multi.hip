@@ -60,9 +60,9 @@ __device__ __forceinline__ uint32_t ring_wrap(uint32_t x) { return x >= QCAP ? x
 template <int K, int D>
 __device__ __forceinline__ void shr_by_byte_into(uint32_t &acc, uint32_t word, uint32_t sel)
 {
-#define KMP_SHR_SDWA(K_, D_, UNUSED_) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_" #D_ " dst_unused:" UNUSED_ " src0_sel:BYTE_" #K_ " src1_sel:DWORD" : "+v"(acc) : "v"(sel), "v"(word))
+#define KMP_SHR_SDWA(K_, D_, UNUSED_) asm volatile("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_" #D_ " dst_unused:" UNUSED_ " src0_sel:BYTE_" #K_ " src1_sel:DWORD" : "+v"(acc) : "v"(sel), "v"(word))
     static_assert((K == 0 && D == 0) || (K == 3 && D == 1) || (K == 2 && D == 2) || (K == 1 && D == 3), "the four start offsets of a dword");
-    if constexpr (D == 0)      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(acc) : "v"(sel), "v"(word));
+    if constexpr (D == 0)      asm volatile("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(acc) : "v"(sel), "v"(word));
     else if constexpr (D == 1) KMP_SHR_SDWA(3, 1, "UNUSED_PRESERVE");
     else if constexpr (D == 2) KMP_SHR_SDWA(2, 2, "UNUSED_PRESERVE");
     else                       KMP_SHR_SDWA(1, 3, "UNUSED_PRESERVE");
@@ -329,28 +329,56 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
 #pragma unroll
                     for (int q4 = 0; q4 < 5; ++q4) x8[q4] = (w[q4] & 0x1F1F1F1Fu) << 3;
                     uint2 e[8];
+                    /* start offsets 4q, 4q + 1: the window is dword q (e[2q]); 4q + 2, 4q + 3: bytes 2 .. 5 from dword q (e[2q + 1]).  The even
+                     * entries are asked for first: their addresses need no v_alignbyte, and the shifts below take them first */
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        e[2 * q4] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        /* start offsets 4q, 4q + 1: the window is dword q; 4q + 2, 4q + 3: bytes 2 .. 5 from dword q */
-                        e[2 * q4] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
                         const uint32_t y8 = __builtin_amdgcn_alignbyte(x8[q4 + 1], x8[q4], 2u);
                         e[2 * q4 + 1] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(y8, 0x00210100u, 0u, false));
                     }
                     /* all eight lookups are on their way before the first result is used */
                     __builtin_amdgcn_sched_barrier(0);
                     /* bit 0 of (word >> byte) is the verdict: the four of a dword land in the four bytes of one register, and a
-                     * v_dot4 with the weights {1, 2, 4, 8} ({16, 32, 64, 128} for the odd dwords) packs them into the hit mask */
-                    uint32_t hmq[2] = {0u, 0u};
+                     * v_dot4 with the weights {1, 2, 4, 8} ({16, 32, 64, 128} for the odd dwords) packs them into the hit mask.  The
+                     * sixteen shifts go round the four registers (an SDWA write into a register and the next instruction that touches it
+                     * need a wait state between them: back to back, the assembler fills it with an s_nop -- an issue slot like any other) */
+                    uint32_t hb[4];
+                    /* two waits for the eight lookups (the LDS answers in order: four outstanding = the even entries are here), not one
+                     * per first use of an entry */
+                    __builtin_amdgcn_s_waitcnt(0xC47F);             /* lgkmcnt(4) */
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        uint32_t hb;
-                        shr_by_byte_into<0, 0>(hb, e[2 * q4].x, w[q4]);
-                        shr_by_byte_into<3, 1>(hb, e[2 * q4].y, w[q4]);
-                        shr_by_byte_into<2, 2>(hb, e[2 * q4 + 1].x, w[q4]);
-                        shr_by_byte_into<1, 3>(hb, e[2 * q4 + 1].y, w[q4 + 1]);
-                        hmq[q4 >> 1] = __builtin_amdgcn_udot4(hb & 0x01010101u, (q4 & 1) ? 0x80402010u : 0x08040201u, hmq[q4 >> 1], false);
-                    }
+                    for (int q4 = 0; q4 < 4; ++q4) shr_by_byte_into<0, 0>(hb[q4], e[2 * q4].x, w[q4]);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) shr_by_byte_into<3, 1>(hb[q4], e[2 * q4].y, w[q4]);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);             /* lgkmcnt(0) */
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) shr_by_byte_into<2, 2>(hb[q4], e[2 * q4 + 1].x, w[q4]);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) shr_by_byte_into<1, 3>(hb[q4], e[2 * q4 + 1].y, w[q4 + 1]);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) hb[q4] &= 0x01010101u;
+                    uint32_t hmq[2];
+                    hmq[0] = __builtin_amdgcn_udot4(hb[0], 0x08040201u, 0u, false);
+                    hmq[1] = __builtin_amdgcn_udot4(hb[2], 0x08040201u, 0u, false);
+                    hmq[0] = __builtin_amdgcn_udot4(hb[1], 0x80402010u, hmq[0], false);
+                    hmq[1] = __builtin_amdgcn_udot4(hb[3], 0x80402010u, hmq[1], false);
                     uint32_t hm = hmq[0] | (hmq[1] << 8);
+#if defined(KMP_MULTI_TUNING) && defined(KMP_TUNE_PAD_VALU)
+                    /* sensitivity probe of tuning builds: KMP_TUNE_PAD_VALU extra two-operand VALU instructions per chunk */
+#pragma unroll
+                    for (int pad = 0; pad < KMP_TUNE_PAD_VALU; ++pad) asm volatile("v_and_b32 %0, %0, %0" : "+v"(hm));
+#endif
+#if defined(KMP_MULTI_TUNING) && defined(KMP_TUNE_PAD_SALU)
+                    {   /* ... and KMP_TUNE_PAD_SALU extra scalar instructions */
+                        uint32_t spad = cb;
+#pragma unroll
+                        for (int pad = 0; pad < KMP_TUNE_PAD_SALU; ++pad) asm volatile("s_and_b32 %0, %0, %0" : "+s"(spad) : : "scc");
+                        asm volatile("" :: "s"(spad));
+                    }
+#endif
                     KMP_MULTI_CUT(1u, hm = 0u);
                     if (ONES || ballot64(hm != 0u) != 0ull) {
                         /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
@@ -362,9 +390,18 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                         /* (the 1-byte patterns over clean padding take care of a lane's own 0x00 themselves, below) */
                         constexpr bool ONES_BY_MASK = ONES && CLEAN && !EMIT;
                         const bool seg = dead_in || (zl & ~last_lanes) != 0ull;
-                        if (seg) nl = nul_limit(15, w, zl, st, dead_in, lane);
-                        else if constexpr (ONES && !ONES_BY_MASK) {
-                            if (zl != 0ull) nl = nul_limit(15, w, 0ull, st, false, lane);           /* the 1-byte patterns below count against nl */
+                        /* (the hit mask is cut down where nl is worked out, inside these branches: applied behind them it became nine
+                         * instructions of selects on every chunk, with nl == 15 in all lanes on nearly all of them) */
+                        if (seg) {
+                            asm volatile("" ::: "memory");
+                            nl = nul_limit(15, w, zl, st, dead_in, lane);
+                            hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
+                        } else if constexpr (ONES && !ONES_BY_MASK) {
+                            if (zl != 0ull) {
+                                asm volatile("" ::: "memory");
+                                nl = nul_limit(15, w, 0ull, st, false, lane);                       /* the 1-byte patterns below count against nl */
+                                hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
+                            }
                         } else if (ballot64(zm != 0u && hm != 0u) != 0ull) {
                             /* A 0x00 in the last lane of its packet (slot padding, a trailer) bars that lane's own later start offsets and
                              * nothing else: zb has bit 4q + b for byte b of dword q (the has-zero masks hold 0x80 per zero byte; v_dot4 packs
@@ -444,7 +481,6 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                                 if constexpr (!EMIT) one_cnt[k] += (found & 0xFFFFu) + (found >> 16);
                             }
                         }
-                        if (ballot64(nl < 15) != 0ull) hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
                         KMP_MULTI_CUT(2u, hm = 0u);
                         const uint64_t hl_ = ballot64(hm != 0u);                    /* the lanes that have a hit */
                         if (hl_ != 0ull) {
