@@ -81,14 +81,20 @@ __device__ __forceinline__ i32x4 make_rsrc(const uint8_t *base, uint32_t bytes)
 
 /* buffer_load_dwordx4 vdst, voffset, srsrc, soffset offen: per-lane offset is a loop constant,
  * the chunk offset lives in an SGPR -- no vector arithmetic per load.  Same asm rules as
- * ring_issue (destination only read after a ring_wait naming it). */
-template <bool NT>
+ * ring_issue (destination only read after a ring_wait naming it).  FRESH: the resource's words have just been written by
+ * v_readfirstlane (make_rsrc), which a VMEM instruction may only read five wait states later: the first loads of a range carry an
+ * s_nop 4; the loads inside the loop do not (their chunk offset comes from the scalar ALU, which needs none) -- the pass is bound by
+ * instruction issue, and an s_nop is an instruction. */
+template <bool NT, bool FRESH = false>
 __device__ __forceinline__ void flat_issue(u32x4 &dst, i32x4 rsrc, uint32_t vo, uint32_t so)
 {
-    if (NT)
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
-    else
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+    if (FRESH) {
+        if (NT) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+        else    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+    } else {
+        if (NT) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+        else    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+    }
 }
 
 /* Per-launch constants of one pattern as the streaming kernels use them: its length and its first 16 bytes as

@@ -106,7 +106,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     const uint32_t vo0 = lane * KMP_LANE_BYTES;
     u32x4 buf[DEPTH];
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+    for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
 
     {
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tables);

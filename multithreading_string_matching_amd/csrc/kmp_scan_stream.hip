@@ -82,7 +82,7 @@ kmp_scan_flat_kernel(const uint8_t *__restrict__ arena, uint64_t n_pkts, uint32_
     const uint32_t vo0 = lane * KMP_LANE_BYTES;
     u32x4 buf[DEPTH];
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+    for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
 
     const uint32_t pid = pat_ids[blockIdx.y];
     const kmp_pattern_dev *gp = patterns + pid;
@@ -241,7 +241,7 @@ kmp_scan_packed_kernel(const uint8_t *__restrict__ arena, const uint64_t *__rest
     const uint32_t vo0 = lane * KMP_LANE_BYTES;
     u32x4 buf[DEPTH];
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) flat_issue<NT>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+    for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
 
     const uint32_t pid = pat_ids[blockIdx.y];
     const kmp_pattern_dev *gp = patterns + pid;

@@ -48,7 +48,7 @@ def _ring_waits(body, n):
 
 
 def _issues(body):
-    return len(re.findall(r";;#ASMSTART\s*\n\s*s_nop 4\s*\n\s*buffer_load_dwordx4 ", body))
+    return len(re.findall(r";;#ASMSTART\s*\n(?:\s*s_nop 4\s*\n)?\s*buffer_load_dwordx4 ", body))
 
 
 def test_no_spills_no_dynamic_register_indexing(stream, multi):
