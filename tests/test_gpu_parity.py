@@ -960,6 +960,66 @@ def test_device_extraction_fixtures(gm, fixture_counts, tokens, key):
     assert gm.scan()[0].tolist() == fx["counts"]
 
 
+def test_frame_batches_loaded_in_two_steps(fixture_counts, tokens):
+    """kmpgpu_load_frames_begin / _finish (the batch tasks of openmp_task.c:157-178 with the extraction on the GPU): two contexts
+    with reserved buffers take the batches of a capture alternately, the upload of the next batch being enqueued before the previous
+    one is finished; accumulated counts == serial.c's.  Call order is checked: finish without begin, begin twice."""
+    import ctypes as C
+    G, H = _lib.gpu_lib(), _lib.host_lib()
+    fx = fixture_counts["fixtures"]["big_udp.pcap:udp"]
+    path = os.path.join(DATA, fx["pcap"]).encode()
+    err = C.create_string_buffer(256)
+    rd = H.kmp_batch_open(path, 0, err)
+    assert rd
+    nb = C.c_uint64()
+    base = H.kmp_batch_file(rd, C.byref(nb))
+    cap, span = 4096, 1 << 16
+    ms = [GpuMatcher(0), GpuMatcher(0)]
+    try:
+        for m in ms:
+            m.set_patterns(tokens)
+            m.set_option(6, 1)                                   # KMPGPU_OPT_ACCUMULATE
+            m.counts_reset()
+            assert G.kmpgpu_reserve(m._ctx, span + 64, cap, span + 64, cap) == 0
+            assert G.kmpgpu_load_frames_finish(m._ctx, None) != 0                       # nothing begun
+        bufs = [(np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint32)) for _ in range(2)]
+        pending, turn, batches, payloads = [None, None], 0, 0, 0
+
+        def finish(k):
+            nonlocal payloads
+            n = C.c_uint64()
+            assert G.kmpgpu_load_frames_finish(ms[k]._ctx, C.byref(n)) == 0, G.kmpgpu_last_error()
+            payloads += n.value
+            ms[k].scan_enqueue()
+            pending[k] = None
+
+        while True:
+            off, cl = bufs[turn]
+            n = H.kmp_batch_next_frames(rd, span, off.ctypes.data, cl.ctypes.data, cap)
+            assert n >= 0
+            if n == 0:
+                break
+            batches += 1
+            ctx = ms[turn]._ctx
+            rc = G.kmpgpu_load_frames_begin(ctx, C.cast(base, _lib.u8p), nb.value, off.ctypes.data_as(_lib.u64p), cl.ctypes.data_as(_lib.u32p), n, 0)
+            assert rc == 0, G.kmpgpu_last_error()
+            assert G.kmpgpu_load_frames_begin(ctx, C.cast(base, _lib.u8p), nb.value, off.ctypes.data_as(_lib.u64p), cl.ctypes.data_as(_lib.u32p), n, 0) != 0   # begun twice
+            pending[turn] = True
+            if pending[turn ^ 1]:
+                finish(turn ^ 1)                                 # the batch before, while this one's upload is queued
+            turn ^= 1
+        for k in (turn, turn ^ 1):
+            if pending[k]:
+                finish(k)
+        assert batches > 5 and payloads == fx["payloads"]
+        total = ms[0].counts_read() + ms[1].counts_read()
+        assert total.tolist() == fx["counts"]
+    finally:
+        for m in ms:
+            m.close()
+        H.kmp_batch_close(rd)
+
+
 def test_device_extraction_crafted_frames(gm, kat_extract, tmp_path):
     """The reference extractors' known answers + random frames, through a pcap file, on the GPU."""
     import struct
