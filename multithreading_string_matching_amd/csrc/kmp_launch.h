@@ -28,7 +28,10 @@ struct kmp_scan_args {
     uint32_t               pkts_per_wave;
     /* packed kernel only */
     const unsigned long long *bitmap;   /* one bit per 16-byte slot of the arena: a payload starts here */
-    const void            *plan;         /* kmp_plan_entry[waves + 1]                                   */
+    const void            *plan;         /* kmp_plan_entry[waves + 1]; fused pass: [units + 1]          */
+    /* fused pass only: the arena in `fused_blocks` regions of `units_per_block` work units each (kmp_plan_shape) */
+    uint32_t               fused_blocks, units_per_block, n_units;
+    uint64_t               span_end;     /* end of the last slot                                        */
     bool                   pad_clean;    /* every byte between a payload's end and the next slot is 0x00 */
     /* match-offset emission (streaming kernels only): kmpgpu_match[emit_cap], running counter */
     void                  *emit_out;
@@ -40,7 +43,11 @@ hipError_t kmp_launch_scan(const kmp_scan_args &a, hipStream_t st);
 hipError_t kmp_launch_scan_flat(const kmp_scan_args &a, hipStream_t st);
 hipError_t kmp_launch_scan_packed(const kmp_scan_args &a, hipStream_t st);
 hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned long long *bitmap, hipStream_t st);
-hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
+/* Where the ranges of a plan are cut (before the closest packet start is taken).  units == 0: entry w at w * step bytes from the first
+ * packet.  Otherwise the arena goes in regions of `region` bytes, one per block of the fused pass, and every region in `units` work
+ * units: `big_units` of `step` bytes, then (the last part of a region, taken when its block is about to run out of work) units of `small`. */
+struct kmp_plan_shape { uint64_t step; uint64_t region; uint32_t units, big_units, small; };
+hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, const kmp_plan_shape &shape,
                            void *plan, hipStream_t st);
 hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks_x, const uint32_t *pat_ids,
                              uint32_t n_ids, unsigned long long *counts, hipStream_t st, const uint32_t *rows = nullptr,

@@ -74,7 +74,7 @@ __device__ __forceinline__ void
 kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
-                      uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
+                      uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb, uint64_t span_end, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
                       const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
@@ -84,29 +84,52 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     const uint32_t rec_words = table_words - KMP_MULTI_REC_W0;
     uint32_t *s_rec = s_dyn;
     uint32_t *s_cnt = s_dyn + rec_words;
-    uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 3u) & ~3u));
+    uint32_t *s_next = s_cnt + n_unique;             /* the block's next unit */
+    uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 1u + 3u) & ~3u));
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
-    /* the plan is cut for 4-wavefront blocks (blocks_x of them, like the other kernels'); a block here takes two of those */
-    const uint32_t gw_ = blockIdx.x * WAVES + wave;
-    const bool idle = gw_ >= nwaves;
-    const uint32_t gw = idle ? 0u : gw_;
-    const uint64_t k0 = plan[gw].k, k1 = idle ? k0 : plan[gw + 1].k;
-    /* the stream starts on the 1 KiB boundary below the first packet (the packed kernel takes the 128-byte line): a chunk
-     * is then exactly one 64-bit word of the packet-start bitmap, no funnel shift per chunk */
-    const uint64_t off_first = plan[gw].off;
-    const uint32_t pre = (uint32_t)(off_first & (uint64_t)(KMP_CHUNK - 1u)), pl = pre >> 4;
-    const uint64_t off0 = off_first - pre;
-    const uint32_t range = (k1 > k0) ? (uint32_t)(plan[gw + 1].off - off0) : 0u;
+    /* WORK UNITS.  The arena is cut into one region per block and every region into `upb` units of a few KiB (whole packets;
+     * plan[] holds first packet and byte offset of every unit, kmp_plan_kernel).  The wavefronts of a block TAKE the units of its
+     * region one after the other off a counter in LDS instead of owning a fixed 1/16 of it: the SIMD issues the instructions of
+     * its oldest wavefront first, so of eight wavefronts with the same work the first is done in 0.43 of the time the last one
+     * takes (profiles/r03_fused_timeline_static_ranges.txt: chunk loops of 79 .. 184 us by hardware wave slot), the block's slot
+     * and LDS stay taken until its last wavefront ends, and the next block cannot start.  With units every wavefront runs at
+     * whatever speed it gets until the region is used up, and they all end within one (small: the last quarter of a region is
+     * cut finer) unit of each other. */
+    const uint32_t ubeg = blockIdx.x * upb;
+    const uint32_t uhave = ubeg < n_units ? min(upb, n_units - ubeg) : 0u;
+    /* positions in the hit queue count from the region's first chunk: a record outlives the unit it was made in */
+    const uint64_t blk_off0 = plan[min(ubeg, n_units)].off & ~(uint64_t)(KMP_CHUNK - 1u);
+    uint32_t u = wave;                               /* the first units go by wavefront number: no LDS yet */
+    bool valid = u < uhave;
 
-    /* The stream starts before the tables are copied: the first DEPTH chunk loads need nothing but the range, and
-     * filling 25-35 KB of LDS from global memory takes longer than they do (an empty range has a record count of
-     * 0: its loads fetch nothing and return zeros). */
-    const i32x4    rsrc = make_rsrc(arena + off0, range);
+    uint64_t k0 = 0ull, k1 = 0ull;
+    uint32_t pl = 0u, range = 0u, ubase = 0u;
+    const unsigned long long *bw = bitmap;
+    i32x4 rsrc;
     const uint32_t vo0 = lane * KMP_LANE_BYTES;
     u32x4 buf[DEPTH];
+    /* unit u: its range, and its first DEPTH chunk loads on their way */
+    auto unit_begin = [&]() {
+        const uint32_t gu = valid ? ubeg + u : 0u;
+        k0 = plan[gu].k;
+        k1 = valid ? plan[gu + 1].k : k0;
+        /* the stream starts on the 1 KiB boundary below the first packet (the packed kernel takes the 128-byte line): a chunk
+         * is then exactly one 64-bit word of the packet-start bitmap, no funnel shift per chunk */
+        const uint64_t off_first = plan[gu].off;
+        const uint32_t pre = (uint32_t)(off_first & (uint64_t)(KMP_CHUNK - 1u));
+        pl = pre >> 4;
+        const uint64_t off0 = off_first - pre;
+        range = (k1 > k0) ? (uint32_t)(plan[gu + 1].off - off0) : 0u;
+        ubase = (uint32_t)(off0 - blk_off0);
+        bw = bitmap + (off0 >> 10);                  /* one word per chunk */
+        rsrc = make_rsrc(arena + off0, range);       /* (an empty range has a record count of 0: its loads fetch nothing and return zeros) */
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+        for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+    };
+    /* The stream starts before the tables are copied: the first DEPTH chunk loads need nothing but the range, and
+     * filling 25-35 KB of LDS from global memory takes longer than they do. */
+    unit_begin();
 
     {
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tables);
@@ -115,6 +138,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     }
     for (uint32_t i = threadIdx.x; i < rec_words; i += WAVES * KMP_WAVE) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
     for (uint32_t i = threadIdx.x; i < n_unique; i += WAVES * KMP_WAVE) s_cnt[i] = 0u;
+    if (threadIdx.x == 0u) *s_next = WAVES;
     __syncthreads();
     const uint32_t *s_bucket = s_fix + KMP_MULTI_BUCKET_W0;
     const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
@@ -123,35 +147,32 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     uint32_t q_head = 0u, q_count = 0u;          /* wave-uniform */
     uint32_t one_cnt[KMP_MULTI_MAX_ONES] = {0u, 0u, 0u, 0u};      /* this lane's matches of the 1-byte patterns that ride along */
 
-    if (range) {
-        const uint64_t b0 = off0 >> 4;
-        const unsigned long long *bw = bitmap + (b0 >> 6);
-
-        unsigned long long hiw[DEPTH];
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[s + 1];
-        unsigned long long low = bw[0];
-        uint64_t kcur = k0 - 1ull;           /* last packet that has started                                   */
-        uint64_t kbase = k0 - 1ull;          /* EMIT: the same, kept in both variants of the payload-end logic */
-        uint32_t last_start = 0u;            /* EMIT: byte position (from the stream's first byte) of that packet's start */
+    {
+        /* state of the unit being read */
+        unsigned long long hiw[DEPTH] = {};
+        unsigned long long low = 0ull;
+        uint64_t kcur = 0ull;                /* last packet that has started                                   */
+        uint64_t kbase = 0ull;               /* EMIT: the same, kept in both variants of the payload-end logic */
+        uint32_t last_start = 0u;            /* EMIT: byte position (from the unit's first chunk) of that packet's start */
         int32_t  remc = 0;                   /* payload bytes of that packet left at the chunk's first byte     */
         bool     dead = false;
         uint32_t cb = 0u, j = 0u;
         /* EMIT only: the start bits of the chunk whose hits are in the queue (the queue is emptied after every chunk there) */
         uint64_t e_st = 0ull;
 
-        /* one match of unique pattern uid at stream position pos */
-        auto count_match = [&](uint32_t uid, uint32_t pos) {
+        /* one match of unique pattern uid at position pos_r of the region */
+        auto count_match = [&](uint32_t uid, uint32_t pos_r) {
             atomicAdd(&s_cnt[uid], 1u);
             if constexpr (EMIT) {
                 /* which packet, and how far into it: from the start bitmap of the chunk the hit lies in (the packet that
                  * holds the hit's lane started at the highest start bit at or below that lane, or before the chunk) */
+                const uint32_t pos = pos_r - ubase;                 /* from the unit's first chunk: the queue is empty between units here */
                 const uint32_t hl = (pos - cb) >> 4;
                 const uint64_t st_le = e_st & ((2ull << hl) - 1ull);
                 const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
                 const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
-                for (uint32_t u = uid_first[uid]; u < uid_first[uid + 1u]; ++u)      /* duplicates of a pattern are reported one by one */
-                    emit_match_as<true>(true, pkt, pos - pstart, uid_ids[u], em);
+                for (uint32_t d = uid_first[uid]; d < uid_first[uid + 1u]; ++d)      /* duplicates of a pattern are reported one by one */
+                    emit_match_as<true>(true, pkt, pos - pstart, uid_ids[d], em);
             }
         };
         /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first} */
@@ -175,20 +196,21 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                         if (eight && m > 8u) {
                             /* rarer: nine bytes or more, the first eight match: the rest straight from the arena (a 0x00 of
                              * the slot padding ends the comparison).  A window never leaves its payload (serial.c:193,198), so it
-                             * never leaves this wavefront's range, which ends with a slot: that bound is what holds for the LAST
+                             * never leaves the arena, which ends with the last slot (span_end): that bound is what holds for the LAST
                              * payload of the index, behind which no packet-start bit follows and the caller's memory may hold
                              * anything (kmpgpu.h: nothing is required, and nothing is read, behind the last slot). */
-                            bool ok = pos + m <= range;
+                            const uint64_t a = blk_off0 + pos;
+                            bool ok = a + m <= span_end;
                             if constexpr (CLEAN) {
                                 /* room only tells 16 / 32 / more there: the exact distance to the next packet start */
-                                const uint64_t a = off0 + pos, b = (a >> 4) + 1ull;
+                                const uint64_t b = (a >> 4) + 1ull;
                                 const unsigned long long w0 = bitmap[b >> 6], w1 = bitmap[(b >> 6) + 1ull];
                                 const uint32_t s6 = (uint32_t)(b & 63ull);
                                 const uint64_t bits = s6 ? ((w0 >> s6) | (w1 << (64u - s6))) : w0;
                                 if (bits != 0ull) ok = ok && (uint64_t)m <= ((b + (uint64_t)__builtin_ctzll(bits)) << 4) - a;
                             }
                             if (ok) {
-                                const uint8_t *tp = arena + off0 + pos;
+                                const uint8_t *tp = arena + a;
                                 const uint8_t *pp = patterns[rec.w >> 8].pat;
                                 for (uint32_t b = 8u; b < m; ++b)
                                     if (tp[b] != pp[b]) { ok = false; break; }
@@ -229,9 +251,9 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             const uint64_t again = ballot64(rest != 0u);
             if (again != 0ull) {
                 /* at most `nproc` (<= 64) records come back; QCAP - 64 stayed at most */
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, 0u));
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(again >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)again, ring_wrap(q_head + q_count)));
                 if (rest != 0u) {
-                    const uint32_t s2 = ring_slot(ring_wrap(q_head + q_count), rank);
+                    const uint32_t s2 = min(at, at - QCAP);
                     q[2u * s2]      = r0;
                     q[2u * s2 + 1u] = make_uint4(r1.x, r1.y, rest | (rem << 16), r1.w);
                 }
@@ -240,6 +262,19 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             walk(T0, T1, rem > i ? rem - i : 0u, r1.w + i, bk, act);
         };
 
+        for (;;) {
+        if (range) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[s + 1];
+            low = bw[0];
+            kcur = k0 - 1ull;
+            kbase = k0 - 1ull;
+            last_start = 0u;
+            remc = 0;
+            dead = false;
+            cb = 0u;
+            j = 0u;
+        }
         while (cb < range) {
             /* packet-start words: use this group's, then ask for the next group's (see kmp_scan_packed_kernel) */
             uint64_t st_[DEPTH];
@@ -330,7 +365,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     for (int q4 = 0; q4 < 5; ++q4) x8[q4] = (w[q4] & 0x1F1F1F1Fu) << 3;
                     uint2 e[8];
                     /* start offsets 4q, 4q + 1: the window is dword q (e[2q]); 4q + 2, 4q + 3: bytes 2 .. 5 from dword q (e[2q + 1]).  The even
-                     * entries are asked for first: their addresses need no v_alignbyte, and the shifts below take them first */
+                     * entries are asked for first: their addresses need no v_alignbyte, and the shifts below take them first.
+                     * (Two 4-byte tables read by one ds_read2st64_b32 would save the five shifts -- the entry's offset is then a v_dot4 of
+                     * the masked text -- and cost a quarter of the pass: 389 against 314 us, profiles/r03_tried_split_pair_table.txt;
+                     * the LDS serves an 8-byte entry in one access, two words 4352 bytes apart in two.) */
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4)
                         e[2 * q4] = *reinterpret_cast<const uint2 *>(s_pair + __builtin_amdgcn_udot4(x8[q4], 0x00210100u, 0u, false));
@@ -380,7 +418,8 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     }
 #endif
                     KMP_MULTI_CUT(1u, hm = 0u);
-                    if (ONES || ballot64(hm != 0u) != 0ull) {
+                    const uint64_t hl0 = ballot64(hm != 0u);
+                    if (ONES || hl0 != 0ull) {
                         /* keep only the start offsets that can count: at least the shortest pattern still inside the payload
                          * and no 0x00 before them (strlen rule, serial.c:191).  Nearly every 0x00 of real traffic and all of the
                          * synthetic input's sit in the LAST lane of a packet (slot padding, trailers): those end nothing but
@@ -402,7 +441,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                                 nl = nul_limit(15, w, 0ull, st, false, lane);                       /* the 1-byte patterns below count against nl */
                                 hm = (nl < 0) ? 0u : (hm & ((2u << nl) - 1u));
                             }
-                        } else if (ballot64(zm != 0u && hm != 0u) != 0ull) {
+                        } else if ((zl & hl0) != 0ull) {
                             /* A 0x00 in the last lane of its packet (slot padding, a trailer) bars that lane's own later start offsets and
                              * nothing else: zb has bit 4q + b for byte b of dword q (the has-zero masks hold 0x80 per zero byte; v_dot4 packs
                              * them), and the hits that stay are those below its lowest bit -- all of them in a lane without a 0x00.  Eleven
@@ -488,11 +527,12 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                             const uint32_t nnew = (uint32_t)__builtin_popcountll(hl_);
                             while (q_count + nnew > QCAP) process_batch(min(q_count, 64u));  /* every batch resolves one hit per record: it ends */
                             const uint32_t w5 = wave_shl1(v.y, sgpr(bn.y));        /* text bytes 20..23 from the lane's first: a hit near its end carries 8 bytes too */
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(hl_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hl_, 0u));
+                            /* (the count of the lanes below starts from the queue's end: no add) */
+                            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(hl_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hl_, ring_wrap(q_head + q_count)));
                             if (hm != 0u) {
-                                const uint32_t slot = ring_slot(ring_wrap(q_head + q_count), rank);
+                                const uint32_t slot = min(at, at - QCAP);
                                 q[2u * slot]      = v;
-                                q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), cb + vo0);
+                                q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), (ubase + cb) + vo0);
                             }
                             q_count += nnew;
                             KMP_MULTI_CUT(3u, (q_head = 0u, q_count = 0u));
@@ -517,11 +557,20 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                 ++j;
             }
         }
+        /* the unit is read: nothing in flight (the last loads lie behind the range and fetched nothing), then the next one */
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+        if (!valid) break;
+        uint32_t t = 0u;
+        if (lane == 0u) t = atomicAdd(s_next, 1u);
+        u = sgpr(t);
+        valid = u < uhave;
+        if (!valid) break;
+        unit_begin();
+        }
         /* what is left in the queue */
         while (q_count != 0u) process_batch(min(q_count, 64u));
     }
-#pragma unroll
-    for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);     /* nothing in flight when the wavefront ends */
 
 #pragma unroll
     for (uint32_t k = 0; k < (ONES ? KMP_MULTI_MAX_ONES : 0u); ++k) {
@@ -546,10 +595,11 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
  * wavefronts that are resident at once, kmp_multi_resident_waves(); a block counts in whichever size its kernel has.) */
 #define KMP_MULTI_PARAMS const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,          \
                          const kmp_plan_entry *__restrict__ plan, const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,         \
-                         uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t nwaves, uint32_t pstride,          \
+                         uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb,             \
+                         uint64_t span_end, uint32_t pstride,                                                                                           \
                          unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,                                 \
                          const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns
-#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, n_short, bmask, n_ones, ones, ablate, nwaves, pstride, partials, em, uid_first, uid_ids, patterns
+#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, n_short, bmask, n_ones, ones, ablate, n_units, upb, span_end, pstride, partials, em, uid_first, uid_ids, patterns
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -577,7 +627,7 @@ kmp_scan_multi_emit_kernel(KMP_MULTI_PARAMS)
 /* LDS one block of `waves` wavefronts of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
 size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves)
 {
-    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + waves * QCAP * 8u) * sizeof(uint32_t);
+    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 1u + 3u) & ~3u) + waves * QCAP * 8u) * sizeof(uint32_t);
 }
 
 /* Which entry point a fused launch takes (0 counting, 1 wide, 2 with offset records), and how many wavefronts of it a CU
@@ -592,11 +642,12 @@ uint32_t kmp_multi_resident_waves(int kind, uint32_t table_words, uint32_t n_uni
     return bw * (by_lds < by_regs ? (by_lds ? by_lds : 1u) : by_regs);
 }
 
-/* Fused multi-pattern pass over a packed arena (bitmap + plan as for kmp_launch_scan_packed). */
+/* Fused multi-pattern pass over a packed arena (packet-start bitmap as for kmp_launch_scan_packed; a.plan: the work units of
+ * a.fused_blocks regions, a.units_per_block each). */
 hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st)
 {
-    if (n_unique == 0 || a.blocks_x == 0) return hipSuccess;
+    if (n_unique == 0 || a.blocks_x == 0 || a.fused_blocks == 0) return hipSuccess;
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const int kind = kmp_multi_kind(a.emit_out != nullptr, a.pad_clean, n_ones);
     const uint32_t bwaves = kmp_multi_block_waves(kind);
@@ -610,8 +661,8 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
 #else
     const uint32_t ablate = 0u;
 #endif
-#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3((a.blocks_x * KMP_BLOCK_WAVES + bwaves - 1u) / bwaves), \
-        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.blocks_x * KMP_BLOCK_WAVES, a.blocks_x, \
+#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3(a.fused_blocks), \
+        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.n_units, a.units_per_block, a.span_end, a.blocks_x, \
         a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
         if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \

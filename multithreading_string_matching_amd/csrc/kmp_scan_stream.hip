@@ -190,14 +190,21 @@ kmp_build_bitmap_kernel(const uint64_t *__restrict__ pkt_off, uint64_t n, unsign
  * BASELINE configs[4], and a block is as slow as its slowest wavefront --, with the closest one it is half of that. */
 __global__ void __launch_bounds__(KMP_BLOCK_THREADS)
 kmp_plan_kernel(const uint64_t *__restrict__ pkt_off, const uint32_t *__restrict__ pkt_len, uint64_t n, uint64_t nwaves,
-                uint64_t bytes_per_wave, kmp_plan_entry *__restrict__ plan)
+                kmp_plan_shape shape, kmp_plan_entry *__restrict__ plan)
 {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > nwaves) return;
     const uint64_t l16 = ((uint64_t)pkt_len[n - 1] + 15ull) & ~15ull;
     const uint64_t end = pkt_off[n - 1] + (l16 < 16ull ? 16ull : l16);
     if (w == nwaves) { plan[w].k = n; plan[w].off = end; return; }
-    const uint64_t target = pkt_off[0] + w * bytes_per_wave;
+    uint64_t target = pkt_off[0];
+    if (shape.units == 0u) target += w * shape.step;
+    else {
+        /* unit u of region r (kmp_launch.h): the big units first, then the small ones; what a region's units overshoot belongs to the next region */
+        const uint64_t r = w / shape.units, u = w % shape.units;
+        const uint64_t in = u <= shape.big_units ? u * shape.step : shape.big_units * shape.step + (u - shape.big_units) * shape.small;
+        target += r * shape.region + (in < shape.region ? in : shape.region);
+    }
     uint64_t lo = 0, hi = n;                       /* lower_bound over the (increasing) offsets */
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
@@ -446,13 +453,13 @@ hipError_t kmp_launch_build_bitmap(const uint64_t *pkt_off, uint64_t n, unsigned
     return hipGetLastError();
 }
 
-hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, uint64_t bytes_per_wave,
+hipError_t kmp_launch_plan(const uint64_t *pkt_off, const uint32_t *pkt_len, uint64_t n, uint64_t nwaves, const kmp_plan_shape &shape,
                            void *plan, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     const uint64_t blocks = (nwaves + 1 + KMP_BLOCK_THREADS - 1) / KMP_BLOCK_THREADS;
     hipLaunchKernelGGL(kmp_plan_kernel, dim3((uint32_t)blocks), dim3(KMP_BLOCK_THREADS), 0, st, pkt_off, pkt_len, n, nwaves,
-                       bytes_per_wave, reinterpret_cast<kmp_plan_entry *>(plan));
+                       shape, reinterpret_cast<kmp_plan_entry *>(plan));
     return hipGetLastError();
 }
 

@@ -99,6 +99,10 @@ struct kmpgpu_ctx {
     unsigned long long *d_bitmap = nullptr;           /* one bit per 16-byte slot: a payload starts here */
     void           *d_plan = nullptr;                 /* kmp_plan_entry[plan_waves + 1] */
     uint64_t        plan_waves = 0, plan_cap = 0;
+    void           *d_uplan = nullptr;                /* fused pass: kmp_plan_entry[uplan_units + 1], the work units of its blocks' regions */
+    uint64_t        uplan_units = 0, uplan_cap = 0;
+    kmp_plan_shape  uplan_shape{};                    /* what d_uplan was cut for */
+    int             fused_unit = 0;                   /* KMPGPU_OPT_FUSED_UNIT */
     uint64_t        uni_off0 = 0;
     uint32_t        uni_stride = 0, uni_len = 0;
     void           *owned_arena = nullptr, *owned_off = nullptr, *owned_len = nullptr;
@@ -172,7 +176,7 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
 {
     /* In units of 4-wavefront blocks.  An explicit KMPGPU_OPT_BLOCKS_PER_CU means CUs x that many (the shape of rounds 1-2:
      * a persistent grid, 4 per CU for the flat kernel, 6 for the packed one); automatic: the flat and the packed kernel
-     * take small ranges and as many blocks as that needs (below), the general kernel 8 per CU, the fused pass twice what
+     * take small ranges and as many blocks as that needs (below), the general kernel 8 per CU, the fused pass what
      * fits a CU (two of its 16-wavefront blocks = 8 of these units). */
     const bool streaming = use_flat(c) || use_packed(c);
     int fused_bpc = 7;
@@ -182,8 +186,10 @@ uint32_t grid_blocks(const kmpgpu_ctx *c, bool emit = false)
         uint32_t waves = 64u;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups)
             waves = std::min(waves, kmp_multi_resident_waves(kmp_multi_kind(emit, c->pad_clean, c->fused_groups.front().n_ones), g.words, g.n_unique));
-        /* twice that: the second half of the blocks starts as the first ones finish, which evens out the ragged end (325 -> 317 us) */
-        fused_bpc = (int)std::max<uint32_t>(1u, 2u * waves / KMP_BLOCK_WAVES);
+        /* ONE round of blocks: inside a block the wavefronts share its region out among themselves as they go (work units, enqueue_pass), so no
+         * block ends long before the others and a second round has nothing to even out (with fixed ranges it had: 325 -> 317 us; with
+         * units one round 303 / 146 / 154 us, two rounds 303 / 158 / 165 us on 1500-byte, Zipf and 64-byte packets, profiles/r03_fused_units_sweep2.txt) */
+        fused_bpc = (int)std::max<uint32_t>(1u, waves / KMP_BLOCK_WAVES);
     }
     const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu
                   : use_fused(c) ? fused_bpc : !streaming ? 8 : use_flat(c) ? 4 : 6;
@@ -255,7 +261,7 @@ void release_arena(kmpgpu_ctx *c, bool keep_buffers = false)
     }
     c->d_arena = nullptr; c->d_off = nullptr; c->d_len = nullptr;
     c->arena_bytes = c->n_pkts = c->payload_bytes = 0;
-    c->uniform = false; c->packed = false; c->pad_clean = false; c->plan_waves = 0;
+    c->uniform = false; c->packed = false; c->pad_clean = false; c->plan_waves = 0; c->uplan_units = 0;
     c->bitmap_live = false;                           /* the buffer itself (1/128 of an arena) is kept for the next arena */
 }
 
@@ -426,7 +432,52 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
      * streaming kernel (mixed lengths) and by the fused multi-pattern pass */
     const bool fused = use_fused(c);
     bool packed = !flat && use_packed(c);
-    if (packed || fused) {
+    bool do_fused = false;
+    if (fused) {
+        /* The fused pass: one region of the arena per block, in work units its wavefronts take one after the other (kmp_scan_multi.hip).
+         * Every wavefront starts with one large unit -- three quarters of its even share of the region --, and the last quarter of the
+         * region lies in a pool of 16 KiB units for whoever is done first: the SIMDs serve their wavefronts in order of age, the first of
+         * a block's wavefronts is through its share when the last one has a third to go.  (Small units throughout cost more than they
+         * balance: every unit starts with a dependent chain of plan entry, descriptor and first loads, ~5 us that the other wavefronts
+         * of the SIMD do not cover -- profiles/r03_tried_all_units_dynamic.txt.) */
+        const uint32_t bwaves = kmp_multi_block_waves(kmp_multi_kind(emit != nullptr, c->pad_clean, c->fused_groups.front().n_ones));
+        const uint64_t fblocks = ((uint64_t)bx * KMP_BLOCK_WAVES + bwaves - 1u) / bwaves;
+        const uint64_t span = c->span_end - c->uni_off0;
+        kmp_plan_shape sh{};
+        sh.region = (((span + fblocks - 1) / fblocks) + 1023ull) & ~1023ull;
+        uint64_t small = c->fused_unit ? (uint64_t)c->fused_unit : 16384ull, pool_div = 4, big = 0;
+#ifdef KMP_MULTI_TUNING
+        if (const char *e = getenv("KMP_FUSED_UNIT")) big = strtoull(e, nullptr, 0) & ~1023ull;          /* 0: from the pool's share */
+        if (const char *e = getenv("KMP_FUSED_SMALL")) small = std::max<uint64_t>(1024ull, strtoull(e, nullptr, 0) & ~1023ull);
+        if (const char *e = getenv("KMP_FUSED_TAIL_DIV")) pool_div = std::max<uint64_t>(1ull, strtoull(e, nullptr, 0));
+#endif
+        uint64_t big_units = bwaves;
+        sh.step = big ? big : std::max<uint64_t>(1024ull, ((sh.region - sh.region / pool_div) / bwaves) & ~1023ull);
+        if (big) big_units = (sh.region - sh.region / pool_div) / sh.step;
+        if (big_units * sh.step > sh.region) big_units = sh.region / sh.step;
+        sh.small = (uint32_t)small;
+        const uint64_t rest = sh.region - big_units * sh.step;
+        const uint64_t upb = big_units + (rest + small - 1) / small;
+        const uint64_t n_units = fblocks * upb;
+        if (sh.region < (1ull << 31) && n_units < (1ull << 31)) {
+            sh.big_units = (uint32_t)big_units; sh.units = (uint32_t)upb;
+            const kmp_plan_shape &o = c->uplan_shape;
+            if (c->uplan_units != n_units || o.step != sh.step || o.region != sh.region || o.units != sh.units || o.big_units != sh.big_units || o.small != sh.small) {
+                if (c->uplan_cap < n_units + 1) {
+                    if (c->d_uplan) HIP_TRY(hipFree(c->d_uplan));
+                    c->d_uplan = nullptr; c->uplan_cap = 0;
+                    HIP_TRY(hipMalloc(&c->d_uplan, (n_units + 1) * 16));
+                    c->uplan_cap = n_units + 1;
+                }
+                HIP_TRY(kmp_launch_plan(c->d_off, c->d_len, c->n_pkts, n_units, sh, c->d_uplan, c->stream));
+                c->uplan_units = n_units; c->uplan_shape = sh;
+            }
+            a.fused_blocks = (uint32_t)fblocks; a.units_per_block = (uint32_t)upb; a.n_units = (uint32_t)n_units; a.span_end = c->span_end;
+            a.bitmap = c->d_bitmap;
+            do_fused = true;
+        }
+    }
+    if (packed) {
         const uint64_t span = c->span_end - c->uni_off0;
         uint64_t bpw = (((span + nwaves - 1) / nwaves) + 15ull) & ~15ull;
         /* whole chunks per range where the ranges are several chunks long: equal-length small payloads then start every range on a
@@ -441,13 +492,14 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
                     HIP_TRY(hipMalloc(&c->d_plan, (nwaves + 1) * 16));
                     c->plan_cap = nwaves + 1;
                 }
-                HIP_TRY(kmp_launch_plan(c->d_off, c->d_len, c->n_pkts, nwaves, bpw ? bpw : 16, c->d_plan, c->stream));
+                kmp_plan_shape sh{};
+                sh.step = bpw ? bpw : 16;
+                HIP_TRY(kmp_launch_plan(c->d_off, c->d_len, c->n_pkts, nwaves, sh, c->d_plan, c->stream));
                 c->plan_waves = nwaves;
             }
             a.bitmap = c->d_bitmap; a.plan = c->d_plan;
         }
     }
-    const bool do_fused = fused && a.plan != nullptr;
 
     auto record = [&](hipEvent_t &e0, hipEvent_t &e1) -> hipError_t {
         e0 = e1 = nullptr;
@@ -467,6 +519,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) {
             kmp_scan_args f = a;
             f.arena = c->d_arena;
+            f.plan = c->d_uplan;
             f.partials = c->d_partials;
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
@@ -567,6 +620,7 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_plan) (void)hipFree(c->d_plan);
+    if (c->d_uplan) (void)hipFree(c->d_uplan);
     free_fused_groups(c);
     if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
     if (c->d_err) (void)hipFree(c->d_err);
@@ -611,6 +665,9 @@ int kmpgpu_set_option(kmpgpu_ctx *c, int key, int64_t value)
         c->kernel_sel = (int)value; return KMPGPU_OK;
     case KMPGPU_OPT_NONTEMPORAL:
         c->nontemporal = value ? 1 : 0; return KMPGPU_OK;
+    case KMPGPU_OPT_FUSED_UNIT:
+        if (value != 0 && (value < 1024 || value > (1 << 20) || (value & 1023))) return fail(KMPGPU_EINVAL, "fused unit must be 0 (auto) or a multiple of 1024 up to 1 MiB");
+        c->fused_unit = (int)value; return KMPGPU_OK;
     default:
         return fail(KMPGPU_EINVAL, "unknown option %d", key);
     }

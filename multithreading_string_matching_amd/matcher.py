@@ -20,6 +20,7 @@ from .host import HostArena
 
 OPT_MODE, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_ACCUMULATE, OPT_NONTEMPORAL = 1, 2, 3, 4, 5, 6, 100
 OPT_REPACK = 7
+OPT_FUSED_UNIT = 8
 KERNEL_AUTO, KERNEL_GENERAL, KERNEL_PACKED, KERNEL_FLAT = 0, 1, 2, 3
 MODE_FILTER, MODE_AUTOMATON = 0, 1
 

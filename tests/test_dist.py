@@ -151,7 +151,7 @@ def test_mpi_dumping_rank_protocol_never_leaves_a_rank_waiting(fail_on, want_rc)
 def test_bench_starts_its_own_ranks_when_no_launcher_did():
     """`python bench.py --gpus 2` with WORLD_SIZE unset (how a driver may call the scale run): the parent starts the two
     ranks itself under torch.distributed.run and hands their exit code on.  In this container there is no GPU, so each rank
-    stops at bench.py's own 'needs an MI355X' check -- which shows that two ranks ran, with RANK/WORLD_SIZE set, and that
+    stops at bench.py's own 'needs an MI355X' check -- which shows that the ranks ran, with RANK/WORLD_SIZE set, and that
     their failure is not swallowed; the parent itself never gets as far as a GPU call."""
     import subprocess
     import sys
@@ -162,5 +162,6 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr
-    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-2000:]
+    # (torch.distributed.run ends the other rank as soon as the first one has failed: it may not get to print its own message)
+    assert r.stderr.count("bench.py needs an MI355X") >= 1, r.stderr[-2000:]
     assert r.stdout.strip() == ""

@@ -91,9 +91,10 @@ def test_packed_kernel_ring_is_unrolled(stream, depth):
 
 def test_fused_kernel_ring_is_unrolled(multi):
     """Three chunks in flight per wavefront; the counting pass must fit 64 VGPRs (two 16-wavefront blocks per CU = 8 wavefronts per SIMD)
-    without spilling, the variants with 1-byte patterns or offset records keep one block per CU (4 per SIMD)."""
+    without spilling, the variants with 1-byte patterns or offset records keep one block per CU (4 per SIMD).  The first loads of a work
+    unit are issued in two places (the wavefront's first unit before the tables are copied, every further one at the end of the unit loop)."""
     assert any("kmp_scan_multi_kernelILi3E" in n for n in multi), list(multi)[:3]
     for name, k in multi.items():
         assert _ring_waits(k["body"], 1) == 3, name
-        assert _issues(k["body"]) == 6, name
+        assert _issues(k["body"]) == 9, name
         assert k["occupancy"] >= (8 if "kmp_scan_multi_kernelI" in name else 4), (name, k["vgprs"])
