@@ -87,9 +87,10 @@ typedef struct kmpgpu_match {
                                         copied once, on the device, into a packed arena owned by
                                         the context (streaming kernels); 0 = scan it in place
                                         with the general kernel                                 */
-#define KMPGPU_OPT_FUSED_UNIT    8   /* fused pass: bytes of a work unit of the pool at the end of a block's region (a multiple
-                                        of 1024 up to 1 MiB; 0 = auto, 16 KiB): a wavefront that is through its own share of
-                                        the region takes the pool's units one after the other */
+#define KMPGPU_OPT_FUSED_UNIT    8   /* fused pass: bytes of a work unit of the pool at the end of a region (a multiple
+                                        of 1024 up to 1 MiB; 0 = auto, 32 KiB; larger where a region has more than ~220 of
+                                        them): a wavefront that is through its own share of the region takes the pool's
+                                        units one after the other */
 #define KMPGPU_OPT_NONTEMPORAL 100   /* 1 (default) = arena loads carry the non-temporal hint (every
                                         byte is read once per pass; measured +10 % on MI355X), 0 =
                                         default cache policy                                   */

@@ -85,10 +85,15 @@ __device__ __forceinline__ i32x4 make_rsrc(const uint8_t *base, uint32_t bytes)
  * v_readfirstlane (make_rsrc), which a VMEM instruction may only read five wait states later: the first loads of a range carry an
  * s_nop 4; the loads inside the loop do not (their chunk offset comes from the scalar ALU, which needs none) -- the pass is bound by
  * instruction issue, and an s_nop is an instruction. */
-template <bool NT, bool FRESH = false>
+template <bool NT, bool FRESH = false, bool SAME_REGS = false>
 __device__ __forceinline__ void flat_issue(u32x4 &dst, i32x4 rsrc, uint32_t vo, uint32_t so)
 {
-    if (FRESH) {
+    if (SAME_REGS) {
+        /* a second place that starts a ring (the fused pass after an empty work unit): into the registers the ring is in, not into
+         * new ones that then have to be copied over (twelve registers the kernel does not have) */
+        if (NT) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+        else    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
+    } else if (FRESH) {
         if (NT) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
         else    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(vo), "s"(rsrc), "s"(so) : "memory");
     } else {

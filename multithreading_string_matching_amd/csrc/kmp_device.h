@@ -63,6 +63,7 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_REC_W0      (KMP_MULTI_FILTER_W0 + KMP_MULTI_PAIR_ENTRIES * 2u)
 #define KMP_MULTI_REC_WORDS   4u
 #define KMP_MULTI_MAX_UNIQUE  256u
+#define KMP_MULTI_MAX_UNITS   256u     /* work units a block's region is cut into at most (their entries sit in LDS, 16 bytes each) */
 #define KMP_MULTI_MIN_LEN     2u
 #define KMP_MULTI_SHORT_LEN   3u       /* patterns up to this length are decided by their bucket entry alone */
 #define KMP_MULTI_MAX_LEN     99u

@@ -30,7 +30,9 @@ struct kmp_scan_args {
     const unsigned long long *bitmap;   /* one bit per 16-byte slot of the arena: a payload starts here */
     const void            *plan;         /* kmp_plan_entry[waves + 1]; fused pass: [units + 1]          */
     /* fused pass only: the arena in `fused_blocks` regions of `units_per_block` work units each (kmp_plan_shape) */
-    uint32_t               fused_blocks, units_per_block, n_units;
+    uint32_t               fused_blocks, units_per_block, n_units;   /* units_per_block: per REGION, which fused_sides (1 or 2) blocks share */
+    uint32_t               fused_sides;
+    uint32_t              *fused_pool;   /* [regions] next unit of the region's pool, all 0 before the launch */
     uint64_t               span_end;     /* end of the last slot                                        */
     bool                   pad_clean;    /* every byte between a payload's end and the next slot is 0x00 */
     /* match-offset emission (streaming kernels only): kmpgpu_match[emit_cap], running counter */

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kmp_device.h"
 #include "kmp_launch.h"
@@ -48,6 +49,16 @@ namespace {
 #else
 #define KMP_MULTI_CUT(n_, stmt_) do { (void)ablate; } while (0)
 #endif
+#ifdef KMP_TUNE_STAMPS
+/* tuning builds only (tools/fused_timeline.py): when each wavefront entered, had its tables, took its first unit from the pool, left its
+ * chunk loop and ended (s_memrealtime, 10 ns ticks) */
+__device__ unsigned long long kmp_tune_stamps[16384 * 8];
+#define KMP_STAMP(k_) do { if (lane == 0u && gw_ < 16384u) kmp_tune_stamps[gw_ * 8u + (k_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KMP_STAMP(k_) do { } while (0)
+#endif
+/* static LDS of a block: tables up to the records, the work units' entries */
+constexpr size_t KMP_MULTI_STATIC_BYTES = (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t) + KMP_MULTI_MAX_UNITS * 16u;
 constexpr uint32_t QCAP = 80u;                  /* queue records per wavefront (32 bytes each): a batch + the lanes of one chunk */
 constexpr uint32_t QBATCH = 64u;                /* records level 2 takes at a time */
 
@@ -74,18 +85,20 @@ __device__ __forceinline__ void
 kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
                       const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
-                      uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb, uint64_t span_end, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
+                      uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb, uint32_t sides, uint32_t *__restrict__ pool_next, uint64_t span_end, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
                       const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
     /* buckets, entries and the filter sit in static LDS: their offsets are compile-time constants that fold
      * into the ds_read offset field; records, counters and one hit queue per wavefront follow dynamically */
     __shared__ __attribute__((aligned(16))) uint32_t s_fix[KMP_MULTI_REC_W0];
+    /* the block's work units {first chunk (bytes from the region's first), bytes, lanes before the first packet | bit 31: no such unit |
+     * packet index, bits 32 up << 8, packet index}: static as well, an address that is a constant costs no register in the chunk loop */
+    __shared__ uint4 s_unit[KMP_MULTI_MAX_UNITS];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const uint32_t rec_words = table_words - KMP_MULTI_REC_W0;
     uint32_t *s_rec = s_dyn;
     uint32_t *s_cnt = s_dyn + rec_words;
-    uint32_t *s_next = s_cnt + n_unique;             /* the block's next unit */
-    uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 1u + 3u) & ~3u));
+    uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 3u) & ~3u));
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
     /* WORK UNITS.  The arena is cut into one region per block and every region into `upb` units of a few KiB (whole packets;
@@ -96,40 +109,92 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
      * and LDS stay taken until its last wavefront ends, and the next block cannot start.  With units every wavefront runs at
      * whatever speed it gets until the region is used up, and they all end within one (small: the last quarter of a region is
      * cut finer) unit of each other. */
-    const uint32_t ubeg = blockIdx.x * upb;
+    /* Regions go by PAIRS of blocks (sides == 2; a grid of one block: 1): blocks p and p + pairs share region p.  Its first units are
+     * the wavefronts' own shares -- 16 for the one block, 16 for the other --, the rest is the pool both take from, off a counter in
+     * global memory.  The hardware starts one block on every CU before it starts a second one anywhere, and the SIMDs serve
+     * the wavefronts of the older block first: with a region of its own the first block of a CU was done at 0.64 of the time the
+     * second one took (profiles/r03_fused_timeline_units_one_round.txt: blocks 0-255 end at 184 us, blocks 256-511 at 284 us).
+     * Nothing here depends on where the blocks of a pair run: whichever is faster takes more of the pool. */
+    const uint32_t pairs = gridDim.x / sides;
+    const uint32_t pair = blockIdx.x % pairs, side = blockIdx.x / pairs;
+    const uint32_t n_own = sides * WAVES;            /* units that are some wavefront's own share */
+    const uint32_t ubeg = pair * upb;
+#ifdef KMP_TUNE_STAMPS
+    const uint32_t gw_ = blockIdx.x * WAVES + wave;
+    uint32_t n_taken = 0u;
+#endif
+    KMP_STAMP(0);
     const uint32_t uhave = ubeg < n_units ? min(upb, n_units - ubeg) : 0u;
     /* positions in the hit queue count from the region's first chunk: a record outlives the unit it was made in */
-    const uint64_t blk_off0 = plan[min(ubeg, n_units)].off & ~(uint64_t)(KMP_CHUNK - 1u);
-    uint32_t u = wave;                               /* the first units go by wavefront number: no LDS yet */
-    bool valid = u < uhave;
-
-    uint64_t k0 = 0ull, k1 = 0ull;
-    uint32_t pl = 0u, range = 0u, ubase = 0u;
-    const unsigned long long *bw = bitmap;
-    i32x4 rsrc;
+    const uint64_t blk_off0_ = plan[min(ubeg, n_units)].off & ~(uint64_t)(KMP_CHUNK - 1u);
+    const uint64_t blk_off0 = (uint64_t)sgpr((uint32_t)blk_off0_) | ((uint64_t)sgpr((uint32_t)(blk_off0_ >> 32)) << 32);
+    /* the unit being read, in bytes from the region's first chunk: the chunk the loop below is at, and the unit's end ... */
+    uint32_t pos = 0u, uend = 0u;
+    uint64_t k0 = 0ull;                              /* ... its first packet ... */
+    /* ... and: bits 0-5 the lanes of its first chunk that lie before its first packet (until that chunk is done), bit 6: the unit after
+     * it has been taken off the counter, bits 8-: that unit's number */
+    uint32_t aux = 0u;
+    /* ONE buffer resource from the region's first chunk to the arena's last slot, never changed (a resource whose record count
+     * moved from unit to unit was kept in spilled registers and read back before every load): a load behind the arena fetches
+     * nothing and returns zeros; a unit's last chunk may reach into the unit behind it -- those lanes are put to zero where the
+     * chunk is looked at (a zero lane can never be a candidate and only ends a packet that ends there anyway).  KMP_NOWHERE: an
+     * offset behind every resource, for the loads of a ring round that has nothing to ask for. */
+    constexpr uint32_t KMP_NOWHERE = 0x80000000u;
+    const uint64_t to_end = span_end - blk_off0;
+    const i32x4 rsrc = make_rsrc(arena + blk_off0, (uint32_t)(to_end < 0x7FFF0000ull ? to_end : 0x7FFF0000ull));
+    /* What the loop below and level 2 need of the arena, they take from the resource (its base: the region's first chunk; its
+     * record count: the bytes up to the arena's last slot, or more than a region has) and from the bitmap word of that chunk: the
+     * chunk loop runs with every scalar register the hardware gives eight wavefronts per SIMD (80 less the compiler's reserve), and
+     * what it does not hold it reads back from spill lanes -- the resource itself, before every load, at the worst. */
+    const unsigned long long *const bwr = bitmap + (blk_off0 >> 10);
+    uint32_t iob = 0u;                               /* the chunk at pos asks for the bytes at pos + iob of the region */
     const uint32_t vo0 = lane * KMP_LANE_BYTES;
     u32x4 buf[DEPTH];
-    /* unit u: its range, and its first DEPTH chunk loads on their way */
-    auto unit_begin = [&]() {
-        const uint32_t gu = valid ? ubeg + u : 0u;
-        k0 = plan[gu].k;
-        k1 = valid ? plan[gu + 1].k : k0;
+    /* unit un of this block as the kernel wants it, from the plan (kmp_plan_kernel) */
+    auto unit_of = [&](uint32_t gu) {
+        const uint64_t ka = plan[gu].k, kb = plan[gu + 1].k;
         /* the stream starts on the 1 KiB boundary below the first packet (the packed kernel takes the 128-byte line): a chunk
          * is then exactly one 64-bit word of the packet-start bitmap, no funnel shift per chunk */
         const uint64_t off_first = plan[gu].off;
         const uint32_t pre = (uint32_t)(off_first & (uint64_t)(KMP_CHUNK - 1u));
-        pl = pre >> 4;
         const uint64_t off0 = off_first - pre;
-        range = (k1 > k0) ? (uint32_t)(plan[gu + 1].off - off0) : 0u;
-        ubase = (uint32_t)(off0 - blk_off0);
-        bw = bitmap + (off0 >> 10);                  /* one word per chunk */
-        rsrc = make_rsrc(arena + off0, range);       /* (an empty range has a record count of 0: its loads fetch nothing and return zeros) */
+        return make_uint4((uint32_t)(off0 - blk_off0), (kb > ka) ? (uint32_t)(plan[gu + 1].off - off0) : 0u, (pre >> 4) | ((uint32_t)(ka >> 32) << 8), (uint32_t)ka);
+    };
+    /* (wave-uniform by construction; sgpr() says so) */
+    auto adopt = [&](uint4 e) {
+        const uint32_t z = sgpr(e.z);
+        pos = sgpr(e.x);
+        uend = pos + ((int32_t)z < 0 ? 0u : sgpr(e.y));
+        aux = z & 63u;
+        if constexpr (!CLEAN || EMIT) k0 = (uint64_t)sgpr(e.w) | ((uint64_t)((z & 0x7FFFFFFFu) >> 8) << 32);
+        iob = (uint32_t)DEPTH * KMP_CHUNK;
+    };
+    /* the next unit of the pool, off the pair's counter (the units' entries are in LDS by then; a number past the region's last unit
+     * finds an entry that says so): where its first chunk is.  (The returning atomic is a vector memory instruction: the compiler
+     * waits for it with vmcnt(0), which the ring's loads -- the last chunks of the unit that is ending -- reach as well.) */
+    auto claim = [&]() {
+        uint32_t t = 0u;
+        if (lane == 0u) t = __hip_atomic_fetch_add(pool_next + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t un = min(n_own + sgpr(t), KMP_MULTI_MAX_UNITS - 1u);
+        aux = (aux & 63u) | 64u | (un << 8);
+        const uint4 e = s_unit[un];
+        return ((int32_t)sgpr(e.z) >= 0 && sgpr(e.y) != 0u) ? sgpr(e.x) : KMP_NOWHERE;
+    };
+    auto next_exists = [&]() { return (int32_t)sgpr(s_unit[aux >> 8].z) >= 0; };
+    auto adopt_next = [&]() { adopt(s_unit[aux >> 8]); };
+    /* the first DEPTH chunk loads of the unit just adopted (every other unit's are issued by the unit before it) */
+    auto prologue = [&](auto again) {
+        const uint32_t at = pos < uend ? pos : KMP_NOWHERE;
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true>(buf[s], rsrc, vo0, (uint32_t)s * KMP_CHUNK);
+        for (int s = 0; s < DEPTH; ++s) flat_issue<NT, true, decltype(again)::value>(buf[s], rsrc, vo0, at + (uint32_t)s * KMP_CHUNK);
     };
     /* The stream starts before the tables are copied: the first DEPTH chunk loads need nothing but the range, and
-     * filling 25-35 KB of LDS from global memory takes longer than they do. */
-    unit_begin();
+     * filling 25-35 KB of LDS from global memory takes longer than they do.  The first units go by wavefront number: no LDS yet. */
+    const uint4 no_unit = make_uint4(0u, 0u, 0x80000000u, 0u);
+    const uint32_t own = side * WAVES + wave;
+    adopt(own < uhave ? unit_of(ubeg + own) : no_unit);
+    prologue(std::false_type{});
+    for (uint32_t i = threadIdx.x; i < KMP_MULTI_MAX_UNITS; i += WAVES * KMP_WAVE) s_unit[i] = i < uhave ? unit_of(ubeg + i) : no_unit;
 
     {
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tables);
@@ -138,8 +203,9 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     }
     for (uint32_t i = threadIdx.x; i < rec_words; i += WAVES * KMP_WAVE) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
     for (uint32_t i = threadIdx.x; i < n_unique; i += WAVES * KMP_WAVE) s_cnt[i] = 0u;
-    if (threadIdx.x == 0u) *s_next = WAVES;
+    KMP_STAMP(1);
     __syncthreads();
+    KMP_STAMP(2);
     const uint32_t *s_bucket = s_fix + KMP_MULTI_BUCKET_W0;
     const uint32_t *s_entry  = s_fix + KMP_MULTI_ENTRY_W0;
     const uint8_t  *s_pair   = reinterpret_cast<const uint8_t *>(s_fix + KMP_MULTI_FILTER_W0);
@@ -153,26 +219,33 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
         unsigned long long low = 0ull;
         uint64_t kcur = 0ull;                /* last packet that has started                                   */
         uint64_t kbase = 0ull;               /* EMIT: the same, kept in both variants of the payload-end logic */
-        uint32_t last_start = 0u;            /* EMIT: byte position (from the unit's first chunk) of that packet's start */
+        uint32_t last_start = 0u;            /* EMIT: byte position (from the region's first chunk) of that packet's start */
         int32_t  remc = 0;                   /* payload bytes of that packet left at the chunk's first byte     */
         bool     dead = false;
-        uint32_t cb = 0u, j = 0u;
+        uint32_t j = 0u;
+        const unsigned long long *bw = bwr;
         /* EMIT only: the start bits of the chunk whose hits are in the queue (the queue is emptied after every chunk there) */
         uint64_t e_st = 0ull;
 
+        /* a word of the packet-start bitmap (wave-uniform; the kernel that also stores offset records reads it with a vector load,
+         * and has to be told so) */
+        auto start_word = [&](const unsigned long long *p) {
+            const unsigned long long x = *p;
+            if constexpr (EMIT) return (unsigned long long)sgpr((uint32_t)x) | ((unsigned long long)sgpr((uint32_t)(x >> 32)) << 32);
+            else return x;
+        };
         /* one match of unique pattern uid at position pos_r of the region */
         auto count_match = [&](uint32_t uid, uint32_t pos_r) {
             atomicAdd(&s_cnt[uid], 1u);
             if constexpr (EMIT) {
                 /* which packet, and how far into it: from the start bitmap of the chunk the hit lies in (the packet that
                  * holds the hit's lane started at the highest start bit at or below that lane, or before the chunk) */
-                const uint32_t pos = pos_r - ubase;                 /* from the unit's first chunk: the queue is empty between units here */
-                const uint32_t hl = (pos - cb) >> 4;
+                const uint32_t hl = (pos_r - pos) >> 4;             /* (the queue is empty between chunks here) */
                 const uint64_t st_le = e_st & ((2ull << hl) - 1ull);
                 const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
-                const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
+                const uint32_t pstart = st_le ? pos + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
                 for (uint32_t d = uid_first[uid]; d < uid_first[uid + 1u]; ++d)      /* duplicates of a pattern are reported one by one */
-                    emit_match_as<true>(true, pkt, pos - pstart, uid_ids[d], em);
+                    emit_match_as<true>(true, pkt, pos_r - pstart, uid_ids[d], em);
             }
         };
         /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first} */
@@ -199,18 +272,17 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                              * never leaves the arena, which ends with the last slot (span_end): that bound is what holds for the LAST
                              * payload of the index, behind which no packet-start bit follows and the caller's memory may hold
                              * anything (kmpgpu.h: nothing is required, and nothing is read, behind the last slot). */
-                            const uint64_t a = blk_off0 + pos;
-                            bool ok = a + m <= span_end;
+                            bool ok = pos + m <= (uint32_t)rsrc.z;      /* (positions count from the region's first chunk, as the resource does) */
                             if constexpr (CLEAN) {
                                 /* room only tells 16 / 32 / more there: the exact distance to the next packet start */
-                                const uint64_t b = (a >> 4) + 1ull;
-                                const unsigned long long w0 = bitmap[b >> 6], w1 = bitmap[(b >> 6) + 1ull];
-                                const uint32_t s6 = (uint32_t)(b & 63ull);
+                                const uint32_t b = (pos >> 4) + 1u;
+                                const unsigned long long w0 = bwr[b >> 6], w1 = bwr[(b >> 6) + 1u];
+                                const uint32_t s6 = b & 63u;
                                 const uint64_t bits = s6 ? ((w0 >> s6) | (w1 << (64u - s6))) : w0;
-                                if (bits != 0ull) ok = ok && (uint64_t)m <= ((b + (uint64_t)__builtin_ctzll(bits)) << 4) - a;
+                                if (bits != 0ull) ok = ok && m <= ((b + (uint32_t)__builtin_ctzll(bits)) << 4) - pos;
                             }
                             if (ok) {
-                                const uint8_t *tp = arena + a;
+                                const uint8_t *tp = reinterpret_cast<const uint8_t *>((uint64_t)(uint32_t)rsrc.x | ((uint64_t)(uint32_t)rsrc.y << 32)) + pos;
                                 const uint8_t *pp = patterns[rec.w >> 8].pat;
                                 for (uint32_t b = 8u; b < m; ++b)
                                     if (tp[b] != pp[b]) { ok = false; break; }
@@ -263,19 +335,28 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
         };
 
         for (;;) {
-        if (range) {
+        if (pos < uend) {
+            bw = bwr + (pos >> 10);                         /* one word per chunk */
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[s + 1];
-            low = bw[0];
+            for (int s = 0; s < DEPTH; ++s) hiw[s] = start_word(bw + s + 1);
+            low = start_word(bw);
             kcur = k0 - 1ull;
             kbase = k0 - 1ull;
             last_start = 0u;
             remc = 0;
             dead = false;
-            cb = 0u;
             j = 0u;
         }
-        while (cb < range) {
+        while (pos < uend) {
+            if (pos + (uint32_t)DEPTH * KMP_CHUNK >= uend) {
+                /* The last round of this unit: everything it has is loaded or in flight, and what this round asks for are the
+                 * first chunks of the NEXT unit -- taken off the block's counter here, its entry read from LDS, the offset moved
+                 * over to it.  The wavefront goes from unit to unit without emptying its ring: a unit
+                 * that starts with plan entry, resource and first loads one after the other costs ~5 us that the other
+                 * wavefronts of the SIMD do not cover (profiles/r03_tried_all_units_dynamic.txt). */
+                asm volatile("" ::: "memory");
+                iob = claim() - pos;
+            }
             /* packet-start words: use this group's, then ask for the next group's (see kmp_scan_packed_kernel) */
             uint64_t st_[DEPTH];
 #pragma unroll
@@ -287,24 +368,27 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) hiw[s] = bw[j + (uint32_t)DEPTH + 1u + (uint32_t)s];
+            for (int s = 0; s < DEPTH; ++s) hiw[s] = start_word(bw + (j + (uint32_t)DEPTH + 1u + (uint32_t)s));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
                 ring_wait<DEPTH - 2>(buf[s], buf[(s + 1) % DEPTH]);
-                if (cb < range) {
+                if (pos < uend) {
                     uint4 v = make_uint4(buf[s].x, buf[s].y, buf[s].z, buf[s].w);
                     const u32x4 bn = buf[(s + 1) % DEPTH];
                     uint64_t st = st_[s];
                     /* (real branches: both cases happen once per range, the selects they would otherwise become cost every chunk) */
-                    if (s == 0 && cb == 0u && pl != 0u) {                               /* lanes before the first packet: not ours */
+                    if (s == 0 && (aux & 63u) != 0u) {                                  /* the unit's first chunk, lanes before its first packet: not ours */
                         asm volatile("" ::: "memory");
+                        const uint32_t pl = aux & 63u;
+                        aux &= ~63u;
                         if (lane < pl) v = make_uint4(0u, 0u, 0u, 0u);
                         st &= ~0ull << pl;
                     }
-                    const uint32_t left = range - cb;
-                    if (left < KMP_CHUNK) {                                             /* bits past the range belong to the next wavefront */
+                    const uint32_t left = uend - pos;
+                    if (left < KMP_CHUNK) {                                             /* the unit ends inside this chunk: what follows is another unit's */
                         asm volatile("" ::: "memory");
+                        if (lane >= (left >> 4)) v = make_uint4(0u, 0u, 0u, 0u);
                         st &= (1ull << (left >> 4)) - 1ull;
                     }
 
@@ -411,7 +495,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
 #endif
 #if defined(KMP_MULTI_TUNING) && defined(KMP_TUNE_PAD_SALU)
                     {   /* ... and KMP_TUNE_PAD_SALU extra scalar instructions */
-                        uint32_t spad = cb;
+                        uint32_t spad = pos;
 #pragma unroll
                         for (int pad = 0; pad < KMP_TUNE_PAD_SALU; ++pad) asm volatile("s_and_b32 %0, %0, %0" : "+s"(spad) : : "scc");
                         asm volatile("" :: "s"(spad));
@@ -509,10 +593,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                                             if (ballot64(ok) != 0ull) {
                                                 const uint64_t st_le = st & ((2ull << lane) - 1ull);
                                                 const uint64_t pkt = kbase + (uint64_t)__builtin_popcountll(st_le);
-                                                const uint32_t pstart = st_le ? cb + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
+                                                const uint32_t pstart = st_le ? pos + (63u - (uint32_t)__builtin_clzll(st_le)) * KMP_LANE_BYTES : last_start;
                                                 const uint32_t row = n_unique - n_ones + k;
                                                 for (uint32_t u = uid_first[row]; u < uid_first[row + 1u]; ++u)
-                                                    emit_match_as<true>(ok, pkt, cb + vo0 + (uint32_t)(4 * q4 + a) - pstart, uid_ids[u], em);
+                                                    emit_match_as<true>(ok, pkt, pos + vo0 + (uint32_t)(4 * q4 + a) - pstart, uid_ids[u], em);
                                             }
                                         }
                                     }
@@ -532,7 +616,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                             if (hm != 0u) {
                                 const uint32_t slot = min(at, at - QCAP);
                                 q[2u * slot]      = v;
-                                q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), (ubase + cb) + vo0);
+                                q[2u * slot + 1u] = make_uint4(w[4], w5, hm | ((uint32_t)min(max(rem, 0), 0xFFFF) << 16), pos + vo0);
                             }
                             q_count += nnew;
                             KMP_MULTI_CUT(3u, (q_head = 0u, q_count = 0u));
@@ -546,31 +630,44 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     }
                     if constexpr (EMIT) {
                         if (st != 0ull) {                                            /* packets that started in this chunk */
-                            last_start = cb + (63u - (uint32_t)__builtin_clzll(st)) * KMP_LANE_BYTES;
+                            last_start = pos + (63u - (uint32_t)__builtin_clzll(st)) * KMP_LANE_BYTES;
                             kbase += (uint64_t)__builtin_popcountll(st);
                         }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                flat_issue<NT>(buf[s], rsrc, vo0, cb + (uint32_t)DEPTH * KMP_CHUNK);
-                cb += KMP_CHUNK;
+                flat_issue<NT>(buf[s], rsrc, vo0, pos + iob);
+                pos += KMP_CHUNK;
                 ++j;
             }
         }
-        /* the unit is read: nothing in flight (the last loads lie behind the range and fetched nothing), then the next one */
+        if (aux & 64u) {
+            /* the unit is read; the next one's first chunks are on their way (or nothing is, if there is none) */
+            if (!next_exists()) break;
+#ifdef KMP_TUNE_STAMPS
+            if (n_taken++ == 0u) KMP_STAMP(6);
+#endif
+            adopt_next();
+        } else {
+            /* an empty unit (its first packet is longer than the unit, or a wavefront that got none at the start): its loads fetched nothing */
 #pragma unroll
-        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
-        if (!valid) break;
-        uint32_t t = 0u;
-        if (lane == 0u) t = atomicAdd(s_next, 1u);
-        u = sgpr(t);
-        valid = u < uhave;
-        if (!valid) break;
-        unit_begin();
+            for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);
+            (void)claim();                   /* (a wavefront without a share of its own: a region shorter than 32 units has no pool either) */
+            if (!next_exists()) break;
+            adopt_next();
+            prologue(std::true_type{});
         }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH; s += 2) ring_wait<0>(buf[s], buf[(s + 1) % DEPTH]);     /* nothing in flight when the wavefront ends */
+        KMP_STAMP(3);
         /* what is left in the queue */
         while (q_count != 0u) process_batch(min(q_count, 64u));
     }
+    KMP_STAMP(4);
+#ifdef KMP_TUNE_STAMPS
+    if (lane == 0u && gw_ < 16384u) kmp_tune_stamps[gw_ * 8u + 7u] = n_taken;
+#endif
 
 #pragma unroll
     for (uint32_t k = 0; k < (ONES ? KMP_MULTI_MAX_ONES : 0u); ++k) {
@@ -582,10 +679,11 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     }
     __syncthreads();
     /* partials[row][blocks_x]: there are fewer blocks here than columns; the columns nobody counts into are zeroed */
-    for (uint32_t i = threadIdx.x; i < n_unique; i += WAVES * KMP_WAVE) {
+    for (uint32_t i = wave * KMP_WAVE + lane; i < n_unique; i += WAVES * KMP_WAVE) {       /* (not threadIdx.x: a register kept, or spilled, through the whole kernel) */
         partials[(uint64_t)i * pstride + blockIdx.x] = s_cnt[i];
         for (uint32_t c = blockIdx.x + gridDim.x; c < pstride; c += gridDim.x) partials[(uint64_t)i * pstride + c] = 0ull;
     }
+    KMP_STAMP(5);
 }
 
 /* Three entry points.  The counting pass over clean padding (every arena this library builds) is held to 64 VGPRs, so that
@@ -596,10 +694,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
 #define KMP_MULTI_PARAMS const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,          \
                          const kmp_plan_entry *__restrict__ plan, const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,         \
                          uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb,             \
-                         uint64_t span_end, uint32_t pstride,                                                                                           \
+                         uint32_t sides, uint32_t *__restrict__ pool_next, uint64_t span_end, uint32_t pstride,                                                                                           \
                          unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,                                 \
                          const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns
-#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, n_short, bmask, n_ones, ones, ablate, n_units, upb, span_end, pstride, partials, em, uid_first, uid_ids, patterns
+#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, n_short, bmask, n_ones, ones, ablate, n_units, upb, sides, pool_next, span_end, pstride, partials, em, uid_first, uid_ids, patterns
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -624,10 +722,17 @@ kmp_scan_multi_emit_kernel(KMP_MULTI_PARAMS)
 
 }  // namespace
 
+#ifdef KMP_TUNE_STAMPS
+extern "C" int kmp_tune_read_stamps(unsigned long long *dst, size_t words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(kmp_tune_stamps), words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 /* LDS one block of `waves` wavefronts of the fused pass takes: static tables + records + counters + one hit queue per wavefront. */
 size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves)
 {
-    return ((size_t)KMP_MULTI_REC_W0 + ((table_words - KMP_MULTI_REC_W0 + n_unique + 1u + 3u) & ~3u) + waves * QCAP * 8u) * sizeof(uint32_t);
+    return KMP_MULTI_STATIC_BYTES + ((size_t)((table_words - KMP_MULTI_REC_W0 + n_unique + 3u) & ~3u) + waves * QCAP * 8u) * sizeof(uint32_t);
 }
 
 /* Which entry point a fused launch takes (0 counting, 1 wide, 2 with offset records), and how many wavefronts of it a CU
@@ -651,7 +756,7 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const int kind = kmp_multi_kind(a.emit_out != nullptr, a.pad_clean, n_ones);
     const uint32_t bwaves = kmp_multi_block_waves(kind);
-    const size_t lds = kmp_multi_lds_bytes(table_words, n_unique, bwaves) - (size_t)KMP_MULTI_REC_W0 * sizeof(uint32_t);      /* the dynamic part */
+    const size_t lds = kmp_multi_lds_bytes(table_words, n_unique, bwaves) - KMP_MULTI_STATIC_BYTES;      /* the dynamic part */
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
     /* tuning builds only (make HIPFLAGS+=-DKMP_MULTI_TUNING; tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the
      * kernel after a stage -- 1 = level 1 alone, 2 = + hit masking, 3 = + queueing; the counts are wrong then.  The product
@@ -662,7 +767,7 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const uint32_t ablate = 0u;
 #endif
 #define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3(a.fused_blocks), \
-        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.n_units, a.units_per_block, a.span_end, a.blocks_x, \
+        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.n_units, a.units_per_block, a.fused_sides, a.fused_pool, a.span_end, a.blocks_x, \
         a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
         if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \

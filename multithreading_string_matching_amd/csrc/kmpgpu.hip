@@ -99,6 +99,8 @@ struct kmpgpu_ctx {
     unsigned long long *d_bitmap = nullptr;           /* one bit per 16-byte slot: a payload starts here */
     void           *d_plan = nullptr;                 /* kmp_plan_entry[plan_waves + 1] */
     uint64_t        plan_waves = 0, plan_cap = 0;
+    uint32_t       *d_pool = nullptr;                 /* fused pass: next pool unit of every region */
+    uint64_t        pool_cap = 0;
     void           *d_uplan = nullptr;                /* fused pass: kmp_plan_entry[uplan_units + 1], the work units of its blocks' regions */
     uint64_t        uplan_units = 0, uplan_cap = 0;
     kmp_plan_shape  uplan_shape{};                    /* what d_uplan was cut for */
@@ -434,32 +436,43 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     bool packed = !flat && use_packed(c);
     bool do_fused = false;
     if (fused) {
-        /* The fused pass: one region of the arena per block, in work units its wavefronts take one after the other (kmp_scan_multi.hip).
-         * Every wavefront starts with one large unit -- three quarters of its even share of the region --, and the last quarter of the
-         * region lies in a pool of 16 KiB units for whoever is done first: the SIMDs serve their wavefronts in order of age, the first of
-         * a block's wavefronts is through its share when the last one has a third to go.  (Small units throughout cost more than they
-         * balance: every unit starts with a dependent chain of plan entry, descriptor and first loads, ~5 us that the other wavefronts
-         * of the SIMD do not cover -- profiles/r03_tried_all_units_dynamic.txt.) */
+        /* The fused pass: one region of the arena per PAIR of blocks, in work units their wavefronts take one after the other
+         * (kmp_scan_multi.hip).  Every wavefront starts with one large unit of its own, and the second half of the region
+         * lies in a pool of 32 KiB units for whoever is done first (profiles/r03_fused_units_sweep4_pair_pools.txt): the SIMDs serve their wavefronts in order of age, so the
+         * first wavefront of a block is through its share when the last one has a third to go, and the block that came to a CU first
+         * is done when the second one has a third to go.  (Small units throughout cost more than they balance: a unit begins
+         * with the dependent chain counter - entry - first loads, which the other wavefronts of the SIMD do not cover --
+         * profiles/r03_tried_all_units_dynamic.txt.) */
         const uint32_t bwaves = kmp_multi_block_waves(kmp_multi_kind(emit != nullptr, c->pad_clean, c->fused_groups.front().n_ones));
-        const uint64_t fblocks = ((uint64_t)bx * KMP_BLOCK_WAVES + bwaves - 1u) / bwaves;
+        uint64_t fblocks = ((uint64_t)bx * KMP_BLOCK_WAVES + bwaves - 1u) / bwaves;
+        const uint32_t sides = fblocks >= 2 ? 2u : 1u;
+        fblocks -= fblocks % sides;
+        const uint64_t regions = fblocks / sides;
         const uint64_t span = c->span_end - c->uni_off0;
         kmp_plan_shape sh{};
-        sh.region = (((span + fblocks - 1) / fblocks) + 1023ull) & ~1023ull;
-        uint64_t small = c->fused_unit ? (uint64_t)c->fused_unit : 16384ull, pool_div = 4, big = 0;
+        sh.region = (((span + regions - 1) / regions) + 1023ull) & ~1023ull;
+        uint64_t small = c->fused_unit ? (uint64_t)c->fused_unit : 32768ull, pool_num = 1, pool_div = 2, big = 0;
 #ifdef KMP_MULTI_TUNING
         if (const char *e = getenv("KMP_FUSED_UNIT")) big = strtoull(e, nullptr, 0) & ~1023ull;          /* 0: from the pool's share */
         if (const char *e = getenv("KMP_FUSED_SMALL")) small = std::max<uint64_t>(1024ull, strtoull(e, nullptr, 0) & ~1023ull);
-        if (const char *e = getenv("KMP_FUSED_TAIL_DIV")) pool_div = std::max<uint64_t>(1ull, strtoull(e, nullptr, 0));
+        if (const char *e = getenv("KMP_FUSED_TAIL_DIV")) { pool_num = 1; pool_div = std::max<uint64_t>(1ull, strtoull(e, nullptr, 0)); }
+        if (const char *e = getenv("KMP_FUSED_TAIL_NUM")) pool_num = std::min<uint64_t>(pool_div, strtoull(e, nullptr, 0));
 #endif
-        uint64_t big_units = bwaves;
-        sh.step = big ? big : std::max<uint64_t>(1024ull, ((sh.region - sh.region / pool_div) / bwaves) & ~1023ull);
-        if (big) big_units = (sh.region - sh.region / pool_div) / sh.step;
+        uint64_t big_units = (uint64_t)sides * bwaves;
+        const uint64_t own_bytes = sh.region - sh.region / pool_div * pool_num;
+        sh.step = big ? big : std::max<uint64_t>(1024ull, (own_bytes / big_units) & ~1023ull);
+        (void)big;
         if (big_units * sh.step > sh.region) big_units = sh.region / sh.step;
+        uint64_t rest = sh.region - big_units * sh.step;
+        /* (a small region: at least four units of the pool per wavefront, or the last unit is all that is left to do for a long time) */
+        if (!c->fused_unit) small = std::min<uint64_t>(small, std::max<uint64_t>(1024ull, (rest / (4ull * big_units ? 4ull * big_units : 1ull)) & ~1023ull));
+        /* a block holds the entries of its units in LDS, KMP_MULTI_MAX_UNITS of them: a large region has larger pool units */
+        const uint64_t room = KMP_MULTI_MAX_UNITS - 1u - big_units;                  /* (one entry stays free: "no such unit") */
+        if ((rest + small - 1) / small > room) small = (((rest + room - 1) / room) + 1023ull) & ~1023ull;
         sh.small = (uint32_t)small;
-        const uint64_t rest = sh.region - big_units * sh.step;
         const uint64_t upb = big_units + (rest + small - 1) / small;
-        const uint64_t n_units = fblocks * upb;
-        if (sh.region < (1ull << 31) && n_units < (1ull << 31)) {
+        const uint64_t n_units = regions * upb;
+        if (sh.region < 0x7FE00000ull && n_units < (1ull << 31)) {                   /* (positions inside a region are 32-bit, kmp_scan_multi.hip) */
             sh.big_units = (uint32_t)big_units; sh.units = (uint32_t)upb;
             const kmp_plan_shape &o = c->uplan_shape;
             if (c->uplan_units != n_units || o.step != sh.step || o.region != sh.region || o.units != sh.units || o.big_units != sh.big_units || o.small != sh.small) {
@@ -472,7 +485,14 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
                 HIP_TRY(kmp_launch_plan(c->d_off, c->d_len, c->n_pkts, n_units, sh, c->d_uplan, c->stream));
                 c->uplan_units = n_units; c->uplan_shape = sh;
             }
+            if (c->pool_cap < regions) {
+                if (c->d_pool) HIP_TRY(hipFree(c->d_pool));
+                c->d_pool = nullptr; c->pool_cap = 0;
+                HIP_TRY(hipMalloc(&c->d_pool, regions * sizeof(uint32_t)));
+                c->pool_cap = regions;
+            }
             a.fused_blocks = (uint32_t)fblocks; a.units_per_block = (uint32_t)upb; a.n_units = (uint32_t)n_units; a.span_end = c->span_end;
+            a.fused_sides = sides; a.fused_pool = c->d_pool;
             a.bitmap = c->d_bitmap;
             do_fused = true;
         }
@@ -521,6 +541,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             f.arena = c->d_arena;
             f.plan = c->d_uplan;
             f.partials = c->d_partials;
+            HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));      /* the regions' pool counters */
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
             HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
@@ -621,6 +642,7 @@ void kmpgpu_destroy(kmpgpu_ctx *c)
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->d_uplan) (void)hipFree(c->d_uplan);
+    if (c->d_pool) (void)hipFree(c->d_pool);
     free_fused_groups(c);
     if (c->d_rest_ids) (void)hipFree(c->d_rest_ids);
     if (c->d_err) (void)hipFree(c->d_err);

@@ -35,32 +35,35 @@ for name, (lens, fixed, n) in (("1M x Zipf 64..9000 B", (zipf(1_000_000), 0, 1_0
     o = torch.from_numpy(off.astype(np.int64)).cuda(); l = torch.from_numpy(ln.astype(np.int32)).cuda()
     torch.cuda.synchronize(); m.synth_fill(a, o, l, sp); m.sync()
     m.attach_arena(a, o, l)
-    for _ in range(20): m.scan_enqueue()
+    for _ in range(300): m.scan_enqueue()           # the clocks are up by then
     m.sync()
-    c, t = m.scan()
+    m.profile_begin(8)
+    for _ in range(4): m.scan_enqueue()
+    ms = m.profile_end(8)
     st = np.zeros(16384 * 8, dtype=np.uint64)
     assert lib.kmp_tune_read_stamps(st.ctypes.data, st.size) == 0
     st = st.reshape(16384, 8)
-    T = st[:, :6].astype(np.int64)
+    T = st[:, :7].astype(np.int64)
     live = T[:, 0] != 0
     t00 = T[live, 0].min()
     us = (T - t00) / 100.0
     nw = int(live.sum())
-    print(f"{name}: kernel by events {t.kernel_ms*1e3:.1f} us, by stamps {us[live, 5].max():.1f} us, wavefronts {nw} (times in us)")
-    first = np.arange(16384) < nw // 2
-    for rnd, sel in (("first round", live & first), ("second round", live & ~first)):
-        print(f"  {rnd}: {int(sel.sum())} wavefronts")
-        pct(us[sel, 0], "entry")
-        pct(us[sel, 2] - us[sel, 0], "entry -> tables ready (barrier)")
-        pct(us[sel, 1] - us[sel, 0], "  of which own copy")
-        pct(us[sel, 3] - us[sel, 2], "chunk loop")
-        pct(us[sel, 3], "chunk loop ends at")
-        pct(us[sel, 5] - us[sel, 3], "loop end -> wavefront end")
-        pct(us[sel, 5], "wavefront ends at")
-    blk = us[:nw - nw % 16].reshape(-1, 16, 6)
+    print(f"{name}: kernel by events {ms.mean()*1e3:.1f} us, by stamps {us[live, 5].max():.1f} us, wavefronts {nw} (times in us)")
+    sel = live
+    pct(us[sel, 0], "entry")
+    pct(us[sel, 2] - us[sel, 0], "entry -> tables ready (barrier)")
+    pct(us[sel, 1] - us[sel, 0], "  of which own copy")
+    took = sel & (st[:, 7] > 0)
+    pct(us[took, 6], "own share done at (took from the pool)")
+    pct(st[sel, 7].astype(np.int64), "units taken from the pool (count)")
+    pct(us[sel, 3], "chunk loop ends at")
+    pct(us[sel, 4] - us[sel, 3], "queue drain")
+    pct(us[sel, 5] - us[sel, 4], "last barrier + partials")
+    pct(us[sel, 5], "wavefront ends at")
+    blk = us[:nw - nw % 16].reshape(-1, 16, 7)
     pct(blk[:, :, 3].max(axis=1) - blk[:, :, 3].min(axis=1), "spread of loop ends inside a block")
-    pct(blk[:, :, 3].max(axis=1) - np.median(blk[:, :, 3], axis=1), "slowest wavefront - median, per block")
-    pct(st[:nw, 7].astype(np.int64) / 1024.0, "range (KiB, not us)")
+    pct(blk[:, :, 3].max(axis=1), "block's last loop end")
+    pct(blk[:, :, 5].max(axis=1), "block ends at")
     np.save(os.path.join(ROOT, "gpurun_out", "r3", f"timeline_{'zipf' if lens is not None else '1500'}.npy"), st)
     del a, o, l
     torch.cuda.empty_cache()

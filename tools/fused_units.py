@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Tuning only (library built with -DKMP_MULTI_TUNING, tools/r3_units.sh): the fused 97-pattern pass against the shape of its work
 units -- KMP_FUSED_UNIT: size of the large units (0 = one per wavefront, the region less the pool shared out evenly),
-KMP_FUSED_SMALL: size of the units of the pool at the end of a region, KMP_FUSED_TAIL_DIV: the pool is 1 / this of the region
-(1000000 = no pool: fixed ranges) -- and the rounds of blocks (KMPGPU_OPT_BLOCKS_PER_CU: 8 = one round of resident blocks)."""
+KMP_FUSED_SMALL: size of the units of the pool at the end of a region, KMP_FUSED_TAIL_NUM / KMP_FUSED_TAIL_DIV: the pool's share
+of the region (1 / 1000000 = no pool: fixed ranges; a fifth value of a configuration is the numerator) -- and the rounds of blocks (KMPGPU_OPT_BLOCKS_PER_CU: 8 = one round of resident blocks)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,8 +39,11 @@ for name, (lens, fixed, n) in (("1M x 1500 B", (None, 1500, 1_000_000)), ("1M x 
                                ("12M x 64 B", (None, 64, 12_000_000))):
     a, o, l, pb = arena(lens, fixed, n)
     ref = None
-    for g, unit, small, div in configs:
+    for cfg in configs:
+        g, unit, small, div = cfg[:4]
+        num = cfg[4] if len(cfg) > 4 else 1
         os.environ["KMP_FUSED_UNIT"] = str(unit); os.environ["KMP_FUSED_SMALL"] = str(small); os.environ["KMP_FUSED_TAIL_DIV"] = str(div)
+        os.environ["KMP_FUSED_TAIL_NUM"] = str(num)
         m.set_option(OPT_BLOCKS_PER_CU, g)
         m.attach_arena(a, o, l)
         got = m.scan()[0]
@@ -51,7 +54,7 @@ for name, (lens, fixed, n) in (("1M x 1500 B", (None, 1500, 1_000_000)), ("1M x 
         m.profile_begin(60)
         for _ in range(60): m.scan_enqueue()
         ms = m.profile_end(60)
-        print(f"{name:22s} blocks/CU {g:3d} unit {unit:6d} small {small:5d} tail 1/{div}: {ms.mean()*1e3:7.1f} us  {pb/ms.mean()/1e6:7.0f} GB/s  frac {pb/ms.mean()/1e6/8000:.3f}", flush=True)
+        print(f"{name:22s} blocks/CU {g:3d} unit {unit:6d} small {small:5d} pool {num}/{div}: {ms.mean()*1e3:7.1f} us  {pb/ms.mean()/1e6:7.0f} GB/s  frac {pb/ms.mean()/1e6/8000:.3f}", flush=True)
     del a, o, l
     torch.cuda.empty_cache()
 m.set_option(OPT_BLOCKS_PER_CU, 0)
