@@ -459,11 +459,13 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         if (const char *e = getenv("KMP_FUSED_TAIL_NUM")) pool_num = std::min<uint64_t>(pool_div, strtoull(e, nullptr, 0));
 #endif
         uint64_t big_units = (uint64_t)sides * bwaves;
-        const uint64_t own_bytes = sh.region - sh.region / pool_div * pool_num;
-        sh.step = big ? big : std::max<uint64_t>(1024ull, (own_bytes / big_units) & ~1023ull);
-        (void)big;
-        if (big_units * sh.step > sh.region) big_units = sh.region / sh.step;
-        uint64_t rest = sh.region - big_units * sh.step;
+        /* (a small region -- a capture of a few hundred KB per block -- goes to the wavefronts whole: a unit of the pool costs a round trip
+         * to the counter in global memory, which a pass of 10 us does not have) */
+        const bool no_pool = sh.region < (1ull << 20) && !big;
+        const uint64_t own_bytes = no_pool ? sh.region : sh.region - sh.region / pool_div * pool_num;
+        sh.step = big ? big : std::max<uint64_t>(1024ull, no_pool ? ((own_bytes + big_units - 1) / big_units + 1023ull) & ~1023ull : (own_bytes / big_units) & ~1023ull);
+        if (!no_pool && big_units * sh.step > sh.region) big_units = sh.region / sh.step;
+        uint64_t rest = no_pool ? 0ull : sh.region - big_units * sh.step;         /* (without a pool the shares reach the region's end: kmp_plan_kernel cuts them there) */
         /* (a small region: at least four units of the pool per wavefront, or the last unit is all that is left to do for a long time) */
         if (!c->fused_unit) small = std::min<uint64_t>(small, std::max<uint64_t>(1024ull, (rest / (4ull * big_units ? 4ull * big_units : 1ull)) & ~1023ull));
         /* a block holds the entries of its units in LDS, KMP_MULTI_MAX_UNITS of them: a large region has larger pool units */
@@ -541,7 +543,8 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             f.arena = c->d_arena;
             f.plan = c->d_uplan;
             f.partials = c->d_partials;
-            HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));      /* the regions' pool counters */
+            if (a.units_per_block > a.fused_sides * kmp_multi_block_waves(kmp_multi_kind(emit != nullptr, c->pad_clean, g.n_ones)))      /* (regions without a pool: nobody asks the counters) */
+                HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));      /* the regions' pool counters */
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
             HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
