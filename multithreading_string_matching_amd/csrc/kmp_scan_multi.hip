@@ -194,14 +194,28 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     const uint32_t own = side * WAVES + wave;
     adopt(own < uhave ? unit_of(ubeg + own) : no_unit);
     prologue(std::false_type{});
-    for (uint32_t i = threadIdx.x; i < KMP_MULTI_MAX_UNITS; i += WAVES * KMP_WAVE) s_unit[i] = i < uhave ? unit_of(ubeg + i) : no_unit;
-
     {
+        /* The block's tables into LDS -- ALL the loads first, then the stores: loop by loop (tables, records, units) every part was a
+         * round trip to L2 of its own, four in a row, ~4 us before the first chunk could be looked at; a pass over 0.7 GB takes 140. */
+        constexpr uint32_t NTHR = WAVES * KMP_WAVE;
+        constexpr uint32_t T4 = KMP_MULTI_REC_W0 / 4u, NIT = (T4 + NTHR - 1u) / NTHR;
         const uint4 *t4 = reinterpret_cast<const uint4 *>(tables);
         uint4 *s4 = reinterpret_cast<uint4 *>(s_fix);
-        for (uint32_t i = threadIdx.x; i < KMP_MULTI_REC_W0 / 4u; i += WAVES * KMP_WAVE) s4[i] = t4[i];
+        const uint32_t tid = threadIdx.x;
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        uint4 tt[NIT];
+#pragma unroll
+        for (uint32_t k = 0; k < NIT; ++k) tt[k] = (tid + k * NTHR < T4) ? t4[tid + k * NTHR] : zero4;
+        const uint32_t r0 = tid < rec_words ? tables[KMP_MULTI_REC_W0 + tid] : 0u;
+        uint4 ue = no_unit;
+        if (tid < uhave) ue = unit_of(ubeg + tid);
+#pragma unroll
+        for (uint32_t k = 0; k < NIT; ++k) if (tid + k * NTHR < T4) s4[tid + k * NTHR] = tt[k];
+        if (tid < rec_words) s_rec[tid] = r0;
+        if (tid < KMP_MULTI_MAX_UNITS) s_unit[tid] = ue;
+        for (uint32_t i = tid + NTHR; i < rec_words; i += NTHR) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];      /* (more than 192 long patterns) */
+        static_assert(KMP_MULTI_MAX_UNITS <= NTHR, "one unit entry per thread");
     }
-    for (uint32_t i = threadIdx.x; i < rec_words; i += WAVES * KMP_WAVE) s_rec[i] = tables[KMP_MULTI_REC_W0 + i];
     for (uint32_t i = threadIdx.x; i < n_unique; i += WAVES * KMP_WAVE) s_cnt[i] = 0u;
     KMP_STAMP(1);
     __syncthreads();
