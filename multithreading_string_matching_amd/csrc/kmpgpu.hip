@@ -466,8 +466,8 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         sh.step = big ? big : std::max<uint64_t>(1024ull, no_pool ? ((own_bytes + big_units - 1) / big_units + 1023ull) & ~1023ull : (own_bytes / big_units) & ~1023ull);
         if (!no_pool && big_units * sh.step > sh.region) big_units = sh.region / sh.step;
         uint64_t rest = no_pool ? 0ull : sh.region - big_units * sh.step;         /* (without a pool the shares reach the region's end: kmp_plan_kernel cuts them there) */
-        /* (a small region: at least four units of the pool per wavefront, or the last unit is all that is left to do for a long time) */
-        if (!c->fused_unit) small = std::min<uint64_t>(small, std::max<uint64_t>(1024ull, (rest / (4ull * big_units ? 4ull * big_units : 1ull)) & ~1023ull));
+        /* (a small region: at least two units of the pool per wavefront, or the last unit is all that is left to do for a long time) */
+        if (!c->fused_unit) small = std::min<uint64_t>(small, std::max<uint64_t>(1024ull, (rest / (2ull * big_units ? 2ull * big_units : 1ull)) & ~1023ull));
         /* a block holds the entries of its units in LDS, KMP_MULTI_MAX_UNITS of them: a large region has larger pool units */
         const uint64_t room = KMP_MULTI_MAX_UNITS - 1u - big_units;                  /* (one entry stays free: "no such unit") */
         if ((rest + small - 1) / small > room) small = (((rest + room - 1) / room) + 1023ull) & ~1023ull;
