@@ -25,7 +25,7 @@ import torch  # noqa: E402,F401
 import multithreading_string_matching_amd as K  # noqa: E402
 from multithreading_string_matching_amd import _lib  # noqa: E402
 from multithreading_string_matching_amd.matcher import (  # noqa: E402
-    KERNEL_AUTO, KERNEL_FLAT, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_KERNEL, OPT_MODE,
+    KERNEL_AUTO, KERNEL_FLAT, KERNEL_GENERAL, KERNEL_PACKED, MODE_AUTOMATON, MODE_FILTER, OPT_BLOCKS_PER_CU, OPT_DEPTH, OPT_FUSED, OPT_FUSED_UNIT, OPT_KERNEL, OPT_MODE,
     OPT_NONTEMPORAL, GpuMatcher)
 
 FIXTURE_KEYS = [
@@ -732,6 +732,48 @@ def _zipf_lengths(n, seed=4):
     p = 1.0 / ranks ** 1.1
     p /= p.sum()
     return (64 + rng.choice(len(ranks), size=n, p=p)).astype(np.uint32)
+
+
+def test_fused_work_units(gm, oracle):
+    """The fused pass cuts the arena into regions (one per pair of blocks) and every region into work units of whole packets: the
+    wavefronts' own shares, then a pool that whoever is done takes from (kmp_scan_multi.hip).  Whatever the size of the pool's
+    units -- 1 KiB: every packet of 1 KiB or more a unit of its own, units without any packet between them; 1 MiB: a pool of two
+    units -- and however many blocks there are, every packet is counted exactly once: counts equal the oracle's, with and without
+    0x00 bytes in the text (the strlen state must not leak from one unit into the next), offset records add up per pattern."""
+    import torch
+    n = 100_000
+    lens = _zipf_lengths(n, seed=9)
+    lens[:6] = [9000, 64, 8999, 1024, 1023, 1025]
+    needle = b"NEEDLE_16B_PATRN"
+    pats = [needle, b"NEEDLE", b"ab", b"the", needle[:9], needle[5:], b"qzx", b"E_1"]
+    for nul_ppm in (0, 1000):
+        sp = K.SynthParams.make(seed=5, needle=needle, plant_permille=200, nul_ppm=nul_ppm)
+        d_arena, d_off, d_len, off, ln, nbytes = _device_synth(gm, n, 0, sp, lens)
+        host = d_arena.cpu().numpy()
+        want = oracle.count(host, off, ln, pats, threads=8)[0].tolist()
+        assert want[0] > 0 and want[2] > 0
+        gm.set_option(OPT_MODE, MODE_FILTER)
+        gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+        gm.set_option(OPT_FUSED, 1)
+        gm.set_patterns(pats)
+        gm.attach_arena(d_arena, d_off, d_len)
+        for bpc in (1, 2, 0):                       # 32 regions of 2 MB (with a pool), 64 of 1 MB, 256 of 260 KB (no pool: shares only)
+            for unit in (0, 1024, 4096, 65536, 1 << 20):
+                gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+                gm.set_option(OPT_FUSED_UNIT, unit)
+                assert gm.scan()[0].tolist() == want, (nul_ppm, bpc, unit)
+        gm.set_option(OPT_BLOCKS_PER_CU, 1)
+        gm.set_option(OPT_FUSED_UNIT, 1024)
+        got, found, counts = gm.scan_offsets(sum(want) + 10)
+        assert found == sum(want) and counts.tolist() == want
+        assert np.bincount(got["pattern"].astype(np.int64), minlength=len(pats)).tolist() == want
+        assert int(got["packet"].max()) < n and bool((got["offset"].astype(np.int64) + np.array([len(p) for p in pats])[got["pattern"]] <= ln[got["packet"]]).all())
+        gm.set_option(OPT_BLOCKS_PER_CU, 0)
+        gm.set_option(OPT_FUSED_UNIT, 0)
+        gm.set_option(OPT_FUSED, 2)
+        gm.set_stream(None)
+        del d_arena, d_off, d_len
+        torch.cuda.empty_cache()
 
 
 def test_full_size_zipf_1m(gm, oracle):
