@@ -57,7 +57,7 @@ hipError_t kmp_launch_reduce(const unsigned long long *partials, uint32_t blocks
 #define KMP_REDUCE_SLICE 4096u            /* partials one block of kmp_reduce_kernel adds up */
 /* more than 16384 partials per pattern are summed by several blocks that ADD to counts[]: the scan kernel zeroes it first (zero_counts) */
 static inline bool kmp_reduce_is_sliced(uint32_t blocks_x) { return blocks_x > 16384u; }
-hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
+hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t cshift, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st);
 size_t kmp_multi_lds_bytes(uint32_t table_words, uint32_t n_unique, uint32_t waves);
 int kmp_multi_kind(bool emit, bool pad_clean, uint32_t n_ones);

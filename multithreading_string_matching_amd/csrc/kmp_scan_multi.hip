@@ -84,7 +84,7 @@ template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES, uint32_t WAVES>
 __device__ __forceinline__ void
 kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
-                      const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bmask,
+                      const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique, uint32_t cshift, uint32_t bmask,
                       uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb, uint32_t sides, uint32_t *__restrict__ pool_next, uint64_t span_end, uint32_t pstride, unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,
                       const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns)
 {
@@ -262,23 +262,25 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                     emit_match_as<true>(true, pkt, pos_r - pstart, uid_ids[d], em);
             }
         };
-        /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first} */
-        auto walk = [&](uint32_t T0, uint32_t T1, uint32_t room, uint32_t pos, uint2 bk, bool act) {
+        /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first};
+         * cls: the bucket's class (0 in a plain group), cw: that class's word {its short patterns, its first record << 16} */
+        auto walk = [&](uint32_t T0, uint32_t T1, uint32_t room, uint32_t pos, uint2 bk, uint32_t cls, uint32_t cw, bool act) {
             uint32_t ent = bk.x;
             uint32_t e = bk.y & 0xFFFFu;
             uint32_t n = act ? (bk.y >> 16) : 0u;                   /* entries left, this one included; a false hit of the filter usually finds an empty bucket */
             while (ballot64(n != 0u) != 0ull) {
                 /* first three bytes (two for a 2-byte pattern: its third byte is 0x00 and skipped) */
                 const bool m3 = n != 0u && __builtin_amdgcn_msad_u8(T0, ent & 0x00FFFFFFu, 0u) == 0u;
-                const uint32_t uid = ent >> 24;
-                const bool lng = uid >= n_short;
+                const uint32_t uid_lo = ent >> 24, uid = uid_lo | (cls << 8);
+                const bool lng = uid_lo >= (cw & 0xFFFFu);
                 bool hit = m3 && !lng && ((ent & 0x00FF0000u) ? 3u : 2u) <= room;
                 if (ballot64(m3 && lng) != 0ull) {
                     /* rare: the first three bytes of a pattern of four bytes or more */
                     if (m3 && lng) {
-                        const uint4 rec = *reinterpret_cast<const uint4 *>(s_rec + (uid - n_short) * KMP_MULTI_REC_WORDS);
-                        const uint32_t m = rec.w & 0xFFu;
-                        const bool eight = T0 == rec.x && ((T1 ^ rec.y) & rec.z) == 0u && m <= room;
+                        const uint2 rec = *reinterpret_cast<const uint2 *>(s_rec + KMP_MULTI_CLS_WORDS + ((cw >> 16) + uid_lo - (cw & 0xFFFFu)) * KMP_MULTI_REC_WORDS);
+                        const uint32_t m = (rec.x >> 8) & 0xFFu;
+                        const uint32_t m47 = m >= 8u ? 0xFFFFFFFFu : m > 4u ? (1u << (8u * (m - 4u))) - 1u : 0u;      /* which of the bytes 4-7 the pattern has */
+                        const bool eight = (T0 >> 24) == (rec.x & 0xFFu) && ((T1 ^ rec.y) & m47) == 0u && m <= room;
                         hit = eight && m <= 8u;
                         if (eight && m > 8u) {
                             /* rarer: nine bytes or more, the first eight match: the rest straight from the arena (a 0x00 of
@@ -297,7 +299,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                             }
                             if (ok) {
                                 const uint8_t *tp = reinterpret_cast<const uint8_t *>((uint64_t)(uint32_t)rsrc.x | ((uint64_t)(uint32_t)rsrc.y << 32)) + pos;
-                                const uint8_t *pp = patterns[rec.w >> 8].pat;
+                                const uint8_t *pp = patterns[uid_ids[uid_first[uid]]].pat;      /* (the first pattern that has this id) */
                                 for (uint32_t b = 8u; b < m; ++b)
                                     if (tp[b] != pp[b]) { ok = false; break; }
                             }
@@ -331,7 +333,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             const uint32_t x2 = q4 == 1u ? t[3] : q4 == 2u ? t[4] : q4 == 3u ? t[5] : t[2];
             const uint32_t T0 = __builtin_amdgcn_alignbyte(x1, x0, i);             /* shift = i & 3 bytes */
             const uint32_t T1 = __builtin_amdgcn_alignbyte(x2, x1, i);
-            const uint2 bk = reinterpret_cast<const uint2 *>(s_bucket)[(uint32_t)__umul24(T0 & bmask, KMP_MULTI_MUL) >> 22];      /* KMP_MULTI_HASH */
+            const uint32_t hx = (uint32_t)__umul24(T0 & bmask, KMP_MULTI_MUL) >> 22;                                           /* KMP_MULTI_HASH */
+            const uint2 bk = reinterpret_cast<const uint2 *>(s_bucket)[hx];
+            const uint32_t cls = hx >> cshift;                                      /* (a plain group: 0) */
+            const uint32_t cw = s_rec[cls];
             q_head = ring_wrap(q_head + nproc);
             q_count -= nproc;
             const uint64_t again = ballot64(rest != 0u);
@@ -345,7 +350,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                 }
                 q_count += (uint32_t)__builtin_popcountll(again);
             }
-            walk(T0, T1, rem > i ? rem - i : 0u, r1.w + i, bk, act);
+            walk(T0, T1, rem > i ? rem - i : 0u, r1.w + i, bk, cls, cw, act);
         };
 
         for (;;) {
@@ -707,11 +712,11 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
  * wavefronts that are resident at once, kmp_multi_resident_waves(); a block counts in whichever size its kernel has.) */
 #define KMP_MULTI_PARAMS const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len, const unsigned long long *__restrict__ bitmap,          \
                          const kmp_plan_entry *__restrict__ plan, const uint32_t *__restrict__ tables, uint32_t table_words, uint32_t n_unique,         \
-                         uint32_t n_short, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb,             \
+                         uint32_t cshift, uint32_t bmask, uint32_t n_ones, uint32_t ones, uint32_t ablate, uint32_t n_units, uint32_t upb,             \
                          uint32_t sides, uint32_t *__restrict__ pool_next, uint64_t span_end, uint32_t pstride,                                                                                           \
                          unsigned long long *__restrict__ partials, Emitter em, const uint32_t *__restrict__ uid_first,                                 \
                          const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns
-#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, n_short, bmask, n_ones, ones, ablate, n_units, upb, sides, pool_next, span_end, pstride, partials, em, uid_first, uid_ids, patterns
+#define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, cshift, bmask, n_ones, ones, ablate, n_units, upb, sides, pool_next, span_end, pstride, partials, em, uid_first, uid_ids, patterns
 
 template <int DEPTH, bool NT, bool CLEAN, bool ONES>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -763,7 +768,7 @@ uint32_t kmp_multi_resident_waves(int kind, uint32_t table_words, uint32_t n_uni
 
 /* Fused multi-pattern pass over a packed arena (packet-start bitmap as for kmp_launch_scan_packed; a.plan: the work units of
  * a.fused_blocks regions, a.units_per_block each). */
-hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t n_short, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
+hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables, uint32_t table_words, uint32_t n_unique, uint32_t cshift, uint32_t bucket_mask, uint32_t n_ones, uint32_t ones,
                                  const uint32_t *uid_first, const uint32_t *uid_ids, hipStream_t st)
 {
     if (n_unique == 0 || a.blocks_x == 0 || a.fused_blocks == 0) return hipSuccess;
@@ -781,7 +786,7 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const uint32_t ablate = 0u;
 #endif
 #define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3(a.fused_blocks), \
-        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, n_short, bucket_mask, n_ones, ones, ablate, a.n_units, a.units_per_block, a.fused_sides, a.fused_pool, a.span_end, a.blocks_x, \
+        dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, cshift, bucket_mask, n_ones, ones, ablate, a.n_units, a.units_per_block, a.fused_sides, a.fused_pool, a.span_end, a.blocks_x, \
         a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
         if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \

@@ -79,7 +79,7 @@ struct kmpgpu_ctx {
         uint32_t *d_ids = nullptr;           /* [n_ids] pattern indices counted by this group            */
         uint32_t *d_rows = nullptr;          /* [n_ids] their unique-pattern row                         */
         uint32_t *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
-        uint32_t  words = 0, n_unique = 0, n_short = 0, bmask = 0, n_ones = 0, ones = 0, n_ids = 0;
+        uint32_t  words = 0, n_unique = 0, cshift = 10, bmask = 0, n_ones = 0, ones = 0, n_ids = 0;
     };
     std::vector<FusedGroup> fused_groups;
     uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
@@ -406,7 +406,15 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
         return KMPGPU_OK;
     }
     const uint32_t bx = grid_blocks(c, emit != nullptr);
-    int rc = ensure_partials(c, (size_t)bx * c->n_pat);
+    /* partial counts: a row per pattern -- or, where the fused pass runs, a row per id of its largest group (a classed group numbers
+     * its patterns by bucket class, up to 1024 ids however few patterns it has) and one per pattern that keeps a pass of its own */
+    size_t part_rows = c->n_pat;
+    if (use_fused(c)) {
+        size_t max_u = 0;
+        for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) max_u = std::max<size_t>(max_u, g.n_unique);
+        part_rows = std::max<size_t>(part_rows, max_u + c->rest_long + c->rest_short);
+    }
+    int rc = ensure_partials(c, (size_t)bx * part_rows);
     if (rc) return rc;
 
     kmp_scan_args a{};
@@ -547,7 +555,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
                 HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));      /* the regions' pool counters */
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
-            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.n_short, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
+            HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.cshift, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
             if (e0) { HIP_TRY(hipEventRecord(e1, c->stream)); c->prof_n++; }
             HIP_TRY(kmp_launch_reduce(c->d_partials, bx, g.d_ids, g.n_ids, d_out, c->stream, g.d_rows, c->accumulate));
             ++nl;
@@ -779,14 +787,20 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     free_fused_groups(c);
     if (c->d_rest_ids) { HIP_TRY(hipFree(c->d_rest_ids)); c->d_rest_ids = nullptr; }
     c->rest_long = c->rest_short = 0;
-    struct HostGroup { std::vector<std::string> uniq; std::vector<uint32_t> ids, rows; };
+    /* a group: its distinct patterns, the row (unique-pattern id of the kernel) of each, the patterns counted by it and their rows.
+     * `classed`: more than 256 rows -- the kernel takes the upper two bits of an id from the bucket's number (the entry has eight),
+     * so the patterns whose key hashes into bucket class c (= bucket >> 8) are numbered 256 c .. 256 c + 255 (kmp_device.h) */
+    struct HostGroup { std::vector<std::string> uniq; std::vector<uint32_t> row; std::vector<uint32_t> ids, rows; bool classed = false;
+                       uint32_t n_cls[4] = {0, 0, 0, 0}, n_cls_short[4] = {0, 0, 0, 0}, overflow = 0; std::vector<uint8_t> bucket_used; };
     std::vector<HostGroup> hg;
-    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> where;        /* pattern -> (group, row) */
     std::vector<uint32_t> rest_l, rest_s;
     /* 1-byte patterns: up to KMP_MULTI_MAX_ONES distinct ones ride along with the first fused group (counted straight
      * off the text registers, no filter, no queue); further ones keep one streaming pass each */
     std::vector<uint8_t> one_bytes;
     std::vector<std::pair<uint32_t, uint32_t>> one_ids;            /* (pattern index, slot) */
+    std::vector<std::string> uniq_all;                             /* the distinct eligible patterns, file order */
+    std::unordered_map<std::string, uint32_t> uniq_of;
+    std::vector<std::pair<uint32_t, uint32_t>> elig;               /* (pattern index, its distinct pattern) */
     for (uint32_t i = 0; i < n_pat; i++) {
         const uint32_t m = pat_len[i];
         if (m == 1) {
@@ -797,17 +811,53 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         }
         if (m < KMP_MULTI_MIN_LEN || m > KMP_MULTI_MAX_LEN) { (m >= 4 ? rest_l : rest_s).push_back(i); continue; }
         const std::string key((const char *)pat[i], m);
-        auto it = where.find(key);
-        if (it == where.end()) {
-            if (hg.empty() || hg.back().uniq.size() == KMP_MULTI_MAX_UNIQUE) hg.emplace_back();
-            it = where.emplace(key, std::make_pair((uint32_t)hg.size() - 1u, (uint32_t)hg.back().uniq.size())).first;
-            hg.back().uniq.push_back(key);
-        }
-        hg[it->second.first].ids.push_back(i);
-        hg[it->second.first].rows.push_back(it->second.second);
+        auto it = uniq_of.find(key);
+        if (it == uniq_of.end()) { it = uniq_of.emplace(key, (uint32_t)uniq_all.size()).first; uniq_all.push_back(key); }
+        elig.emplace_back(i, it->second);
     }
-    if (where.size() < 2) {                       /* nothing to fuse: every pattern keeps its own pass (c->d_ids) */
+    if (uniq_all.size() < 2) {                    /* nothing to fuse: every pattern keeps its own pass (c->d_ids) */
         return KMPGPU_OK;
+    }
+    /* Which group a distinct pattern goes to.  Up to 256 of them: one group, rows in file order (short ones first, below).  More: the
+     * 2-byte patterns (entered under every third byte: 32 buckets each, in all classes) and, if 1-byte patterns ride along, the first
+     * patterns of the file fill plain groups of 256; everything else goes to classed groups of up to 1024 -- first fit, a pattern
+     * whose class is full (256 per class, 255 short ones) or whose bucket would overflow the entry list waits for the next group. */
+    std::vector<std::pair<uint32_t, uint32_t>> place(uniq_all.size());        /* distinct pattern -> (group, index in its uniq) */
+    auto key_class = [](const std::string &p) {
+        const uint32_t w24 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | ((uint32_t)(uint8_t)p[2] << 16);
+        return KMP_MULTI_HASH(w24 & KMP_MULTI_KEYMASK);
+    };
+    {
+        const bool big = uniq_all.size() > KMP_MULTI_MAX_UNIQUE;
+        std::vector<uint32_t> plain, classed;
+        for (uint32_t u = 0; u < uniq_all.size(); u++) (!big || uniq_all[u].size() == 2 ? plain : classed).push_back(u);
+        if (big && plain.empty() && !one_bytes.empty()) {                     /* the 1-byte patterns need a plain first group */
+            const size_t take = std::min<size_t>(classed.size(), KMP_MULTI_MAX_UNIQUE);
+            plain.assign(classed.begin(), classed.begin() + take);
+            classed.erase(classed.begin(), classed.begin() + take);
+        }
+        for (uint32_t u : plain) {
+            if (hg.empty() || hg.back().uniq.size() == KMP_MULTI_MAX_UNIQUE) hg.emplace_back();
+            place[u] = {(uint32_t)hg.size() - 1u, (uint32_t)hg.back().uniq.size()};
+            hg.back().uniq.push_back(uniq_all[u]);
+        }
+        const size_t first_classed = hg.size();
+        for (uint32_t u : classed) {
+            const std::string &p = uniq_all[u];
+            const uint32_t b = key_class(p), cl = b >> 8;
+            const bool shortp = p.size() <= KMP_MULTI_SHORT_LEN;
+            size_t gi = first_classed;
+            for (; gi < hg.size(); gi++) {
+                HostGroup &h = hg[gi];
+                if (h.n_cls[cl] < 256u && (!shortp || h.n_cls_short[cl] < 255u) && h.overflow + (h.bucket_used[b] ? 1u : 0u) <= KMP_MULTI_MAX_ENTRIES) break;
+            }
+            if (gi == hg.size()) { hg.emplace_back(); hg.back().classed = true; hg.back().bucket_used.assign(KMP_MULTI_BUCKETS, 0); }
+            HostGroup &h = hg[gi];
+            h.n_cls[cl]++; if (shortp) h.n_cls_short[cl]++;
+            if (h.bucket_used[b]) h.overflow++; else h.bucket_used[b] = 1;
+            place[u] = {(uint32_t)gi, (uint32_t)h.uniq.size()};
+            h.uniq.push_back(p);
+        }
     }
     bool first_group = true;
     for (HostGroup &h : hg) {
@@ -816,22 +866,28 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         uint32_t ones = 0;
         for (uint32_t k = 0; k < n_ones; k++) ones |= (uint32_t)one_bytes[k] << (8 * k);
         first_group = false;
-        /* number the unique patterns short ones (2 or 3 bytes: decided by their bucket entry alone) first */
-        uint32_t n_short = 0;
-        {
-            std::vector<uint32_t> order, new_row(U);
-            for (uint32_t u = 0; u < U; u++) if (h.uniq[u].size() <= KMP_MULTI_SHORT_LEN) order.push_back(u);
-            n_short = (uint32_t)order.size();
-            for (uint32_t u = 0; u < U; u++) if (h.uniq[u].size() > KMP_MULTI_SHORT_LEN) order.push_back(u);
-            std::vector<std::string> uq(U);
-            for (uint32_t r = 0; r < U; r++) { uq[r] = h.uniq[order[r]]; new_row[order[r]] = r; }
-            h.uniq.swap(uq);
-            for (uint32_t &r : h.rows) r = new_row[r];
+        /* rows: short patterns (2 or 3 bytes: decided by their bucket entry alone) first -- in the whole group, or in every class */
+        uint32_t cls_short[4] = {0, 0, 0, 0}, cls_n[4] = {0, 0, 0, 0}, rec_base[4] = {0, 0, 0, 0}, rows_n = 0;
+        std::vector<uint32_t> cls_of(U, 0u);
+        h.row.assign(U, 0u);
+        for (uint32_t u = 0; u < U; u++) {
+            cls_of[u] = h.classed ? key_class(h.uniq[u]) >> 8 : 0u;
+            if (h.uniq[u].size() <= KMP_MULTI_SHORT_LEN) cls_short[cls_of[u]]++;
         }
-        const uint32_t n_long = U - n_short;
-        std::vector<uint32_t> where_first(U, UINT32_MAX);                         /* a pattern index for every row */
-        for (size_t i = 0; i < h.ids.size(); i++) where_first[h.rows[i]] = std::min(where_first[h.rows[i]], h.ids[i]);
-        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (size_t)n_long * KMP_MULTI_REC_WORDS, 0u);
+        {
+            uint32_t next_short[4] = {0, 0, 0, 0}, next_long[4] = {cls_short[0], cls_short[1], cls_short[2], cls_short[3]};
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t cl = cls_of[u];
+                const uint32_t in = h.uniq[u].size() <= KMP_MULTI_SHORT_LEN ? next_short[cl]++ : next_long[cl]++;
+                h.row[u] = cl * 256u + in;
+                cls_n[cl] = std::max(cls_n[cl], in + 1u);
+                rows_n = std::max(rows_n, h.row[u] + 1u);
+            }
+            for (uint32_t cl = 1; cl < 4; cl++) rec_base[cl] = rec_base[cl - 1] + (cls_n[cl - 1] - cls_short[cl - 1]);
+        }
+        const uint32_t n_long = rec_base[3] + (cls_n[3] - cls_short[3]);
+        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)n_long * KMP_MULTI_REC_WORDS, 0u);
+        for (uint32_t cl = 0; cl < 4; cl++) tab[KMP_MULTI_REC_W0 + cl] = cls_short[cl] | (rec_base[cl] << 16);
         uint32_t *bucket = tab.data() + KMP_MULTI_BUCKET_W0;
         uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
         std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
@@ -856,20 +912,19 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
                 if (l.empty() || l.back() != u) l.push_back(u);
                 if (p.size() >= 3) break;
             }
-            if (u < n_short) continue;
-            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)(u - n_short) * KMP_MULTI_REC_WORDS;
-            for (uint32_t b = 0; b < p.size() && b < 8u; b++) {
-                rec[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
-                if (b >= 4u) rec[2] |= 0xFFu << (8 * (b & 3));
-            }
-            rec[3] = (uint32_t)p.size() | (where_first[u] << 8);       /* the rest of it: kmp_pattern_dev[that index].pat */
+            if (p.size() <= KMP_MULTI_SHORT_LEN) continue;
+            const uint32_t cl = cls_of[u];
+            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)(rec_base[cl] + (h.row[u] & 255u) - cls_short[cl]) * KMP_MULTI_REC_WORDS;
+            rec[0] = (uint32_t)(uint8_t)p[3] | ((uint32_t)p.size() << 8);          /* byte 3 (the entry has bytes 0-2), the length */
+            for (uint32_t b = 4; b < p.size() && b < 8u; b++) rec[1] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
         }
         uint32_t pos = 0;
         for (uint32_t hh = 0; hh < KMP_MULTI_BUCKETS; hh++) {
             for (size_t q = 0; q < lists[hh].size(); q++) {
-                const std::string &p = h.uniq[lists[hh][q]];
+                const uint32_t u = lists[hh][q];
+                const std::string &p = h.uniq[u];
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : 0u;      /* never 0x00 inside a pattern */
-                const uint32_t ent = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | (third << 16) | (lists[hh][q] << 24);
+                const uint32_t ent = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | (third << 16) | ((h.row[u] & 255u) << 24);
                 if (q == 0) { bucket[2 * hh] = ent; continue; }       /* the first entry sits in the bucket itself */
                 if (pos >= KMP_MULTI_MAX_ENTRIES) return fail(KMPGPU_EINVAL, "kmpgpu_set_patterns: fused tables: entry list overflow");
                 entry[pos++] = ent;
@@ -877,13 +932,21 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             const uint32_t extra = lists[hh].empty() ? 0u : (uint32_t)lists[hh].size() - 1u;
             bucket[2 * hh + 1] = (pos - extra) | ((uint32_t)lists[hh].size() << 16);
         }
-        /* the 1-byte patterns that ride along: rows U .. U + n_ones - 1 */
+        /* the patterns this group counts, and the row of each */
+        for (const auto &e : elig) {
+            const auto &pl = place[e.second];
+            if (&hg[pl.first] != &h) continue;
+            h.ids.push_back(e.first);
+            h.rows.push_back(h.row[pl.second]);
+        }
+        /* the 1-byte patterns that ride along: rows behind the group's own */
         if (n_ones)
-            for (const auto &oi : one_ids) { h.ids.push_back(oi.first); h.rows.push_back(U + oi.second); }
-        /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) */
-        std::vector<uint32_t> uid_first(U + n_ones + 1, 0u), uid_ids(h.ids.size());
+            for (const auto &oi : one_ids) { h.ids.push_back(oi.first); h.rows.push_back(rows_n + oi.second); }
+        /* row -> the pattern indices that share it, for the offset records (duplicates are reported one by one) and for the
+         * rest of a pattern of nine bytes or more (kmp_pattern_dev[first of them].pat) */
+        std::vector<uint32_t> uid_first(rows_n + n_ones + 1, 0u), uid_ids(h.ids.size());
         for (uint32_t r : h.rows) uid_first[r + 1]++;
-        for (uint32_t u = 0; u < U + n_ones; u++) uid_first[u + 1] += uid_first[u];
+        for (uint32_t u = 0; u < rows_n + n_ones; u++) uid_first[u + 1] += uid_first[u];
         { std::vector<uint32_t> fill(uid_first.begin(), uid_first.end() - 1);
           for (size_t i = 0; i < h.ids.size(); i++) uid_ids[fill[h.rows[i]]++] = h.ids[i]; }
         c->fused_groups.emplace_back();
@@ -898,7 +961,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         HIP_TRY(up(&g.d_rows, h.rows));
         HIP_TRY(up(&g.d_uid_first, uid_first));
         HIP_TRY(up(&g.d_uid_ids, uid_ids));
-        g.words = (uint32_t)tab.size(); g.n_unique = U + n_ones; g.n_short = n_short; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
+        g.words = (uint32_t)tab.size(); g.n_unique = rows_n + n_ones; g.cshift = h.classed ? 8u : 10u; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
         c->n_multi_unique += U;
     }
     std::vector<uint32_t> rest(rest_l);

@@ -1535,3 +1535,70 @@ def test_fused_pass_table_shapes(gm, oracle):
         gm.set_option(OPT_FUSED, fused)
         assert gm.scan()[0].tolist() == want.tolist(), fused
     gm.set_option(OPT_FUSED, 2)
+
+
+@pytest.mark.parametrize("n_pats,with_short", [(257, True), (700, False), (1500, True), (3000, True)])
+def test_fused_classed_groups(gm, oracle, n_pats, with_short):
+    """More than 256 distinct patterns: groups of up to 1024 whose ids take their upper two bits from the bucket class (kmp_device.h),
+    2-byte patterns in plain groups beside them, 1-byte patterns riding along with the first (plain) group.  Patterns over a
+    three-letter alphabet, so that buckets hold several of them, classes fill unevenly, many share 3 / 8 / 20 bytes, and the text
+    is full of matches; duplicates in the list; NULs in the text; counts and offset records against the oracle, clean and dirty
+    slot padding (the unclean variant is a kernel of its own)."""
+    import torch
+    rng = random.Random(1000 + n_pats)
+    alpha = b"abc"
+    seen, pats = set(), []
+    while len(seen) < n_pats:
+        L = rng.choice((3, 3, 4, 4, 5, 6, 7, 8, 9, 9, 10, 12, 17, 24, 33, 40))
+        p = bytes(rng.choice(alpha) for _ in range(L))
+        if p not in seen:
+            seen.add(p); pats.append(p)
+    if with_short:
+        pats += [b"ab", b"ca", b"bb", b"a", b"c"]
+    pats += pats[5:25]                                                                    # duplicates: reported per index
+    rng.shuffle(pats)
+    payloads = []
+    for k in range(300):
+        L = rng.randrange(0, 700)
+        b = bytearray(rng.choice(alpha) for _ in range(L))
+        if L and rng.random() < 0.25:
+            b[rng.randrange(L)] = 0
+        payloads.append(bytes(b))
+    arena = K.HostArena.from_payloads(payloads)
+    want = oracle.count(arena.bytes, arena.off, arena.len, pats, threads=8)[0].tolist()
+    assert sum(1 for w in want if w) > len(want) // 2
+    gm.set_stream(None)
+    gm.set_option(OPT_MODE, MODE_FILTER)
+    gm.set_option(OPT_KERNEL, KERNEL_AUTO)
+    gm.set_option(OPT_FUSED, 1)
+    gm.set_patterns(pats)
+    gm.load_arena(arena)
+    for bpc in (0, 1):
+        gm.set_option(OPT_BLOCKS_PER_CU, bpc)
+        assert gm.scan()[0].tolist() == want, bpc
+    gm.set_option(OPT_BLOCKS_PER_CU, 0)
+    got, found, counts = gm.scan_offsets(sum(want) + 10)
+    assert found == sum(want) and counts.tolist() == want
+    assert np.bincount(got["pattern"].astype(np.int64), minlength=len(pats)).tolist() == want
+    lens = np.array([len(p) for p in pats])
+    assert bool((got["offset"].astype(np.int64) + lens[got["pattern"]] <= arena.len[got["packet"]]).all())
+    # every record is a match: the pattern stands at that offset of that packet
+    for r in got[:: max(1, len(got) // 2000)]:
+        p = pats[int(r["pattern"])]
+        o = int(arena.off[int(r["packet"])]) + int(r["offset"])
+        assert bytes(arena.bytes[o:o + len(p)]) == p
+    # dirty slot padding: the text goes on behind every payload (the lengths come from the index)
+    dirty = np.array(arena.bytes)
+    fill = bytes(rng.choice(alpha) for _ in range(64))
+    for o, l in zip(arena.off, arena.len):
+        o, l = int(o), int(l)
+        end = o + max(16, (l + 15) // 16 * 16)
+        dirty[o + l:end] = np.frombuffer(fill[:end - o - l], dtype=np.uint8)
+    d_arena = torch.from_numpy(dirty).cuda()
+    d_off = torch.from_numpy(arena.off.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(arena.len.astype(np.int32)).cuda()
+    torch.cuda.synchronize()
+    gm.attach_arena(d_arena, d_off, d_len)
+    assert gm.scan()[0].tolist() == want
+    gm.set_option(OPT_FUSED, 2)
+
