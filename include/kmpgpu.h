@@ -67,8 +67,9 @@ typedef struct kmpgpu_match {
                                         take ~6-16 KiB per wavefront, however many blocks that is */
 #define KMPGPU_OPT_DEPTH         3   /* chunk loads in flight per wavefront: 2..6, 8; 0 = auto */
 #define KMPGPU_OPT_FUSED         4   /* 1 = fused multi-pattern pass: the patterns of 2..99
-                                        bytes are counted in ONE read of a packed arena per 256
-                                        distinct patterns (up to four 1-byte patterns ride along,
+                                        bytes are counted in ONE read of a packed arena per 1024
+                                        distinct patterns (256 where 2-byte patterns are among
+                                        them; up to four 1-byte patterns ride along,
                                         further ones keep one read each); 0 = off; 2 = auto
                                         (default): fused from 2 such unique patterns on         */
 #define KMPGPU_OPT_KERNEL        5   /* 0 auto: slots back to back -> packed streaming kernel, or

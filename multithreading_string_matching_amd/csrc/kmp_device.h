@@ -37,9 +37,10 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
  *   [2048, 2560)     entries: b0 | b1 << 8 | b2 << 16 | (unique-pattern id & 255) << 24; b2 = 0x00 for a 2-byte pattern
  *                    (v_msad_u8 skips a 0x00 reference byte: it matches whatever follows).  A group of up to 256 unique
  *                    patterns numbers them 0 .. 255, short ones (2 or 3 bytes) first: id < n_short means the entry decides
- *                    alone.  A CLASSED group holds up to 1024 (no 2-byte ones): bucket class c = bucket >> 8 numbers its
- *                    patterns 256 c .. 256 c + 255, short ones first in every class, and the kernel takes the upper two
- *                    bits of an id from the bucket it came through (kmp_scan_multi_kernel's cshift: 8; plain groups 10).
+ *                    alone.  A CLASSED group holds up to 1024 (no 2-byte ones): the patterns of bucket class c = bucket >> 7
+ *                    (eight classes, up to 256 patterns each) are numbered from the class's first id on, short ones first,
+ *                    and the kernel adds that first id to the entry's eight bits (kmp_scan_multi_kernel's cshift: 7; a
+ *                    plain group is one class, cshift 10).
  *   [2560, 4672)     filter over the first three text bytes, as a PAIR table: the bytes are taken by their low five bits
  *                    (codes c = b & 31), and entry KMP_MULTI_PAIR(c1, c2) = c1 + 33 * c2 (8 bytes, 1056 entries) holds
  *                      word 0: bit c0 set  <=>  some pattern starts c0 c1 c2      ("which byte may stand BEFORE c1 c2")
@@ -51,9 +52,9 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
  *                    (c0, c1).  No hash: letters of one case never share a bit, text gives no false hit (round 2's first
  *                    filter, 16384 hashed slots: 42 % of its hits on lower-case text were collisions).  The factor 33
  *                    spreads the entries over the bank pairs by c1 + c2 (one letter alone covers 26 of 32).
- *   [4672, 4676)     one word per bucket class: short patterns of the class | first record of the class << 16
- *   [4676, ...)      one 2-word record per LONG unique pattern (4+ bytes; record = first of its class + (id & 255) - the
- *                    class's short ones): byte 3 | m << 8, bytes 4-7 (a pattern of nine bytes or more compares its rest
+ *   [4672, 4680)     one word per bucket class, KMP_MULTI_CLS_WORD: its short patterns | its first record << 9 | its first id << 20
+ *   [4680, ...)      one 2-word record per LONG unique pattern (4+ bytes; record = first of its class + the entry's eight
+ *                    bits - the class's short ones): byte 3 | m << 8, bytes 4-7 (a pattern of nine bytes or more compares its rest
  *                    against kmp_pattern_dev[].pat of the first pattern that has this id, uid_ids[uid_first[id]])
  * The first 4672 words live in static LDS (their offsets fold into the ds_read offset field). */
 #define KMP_MULTI_BUCKETS     1024u
@@ -65,7 +66,9 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_FILTER_W0   2560u
 #define KMP_MULTI_PAIR_ENTRIES 1056u
 #define KMP_MULTI_REC_W0      (KMP_MULTI_FILTER_W0 + KMP_MULTI_PAIR_ENTRIES * 2u)
-#define KMP_MULTI_CLS_WORDS   4u
+#define KMP_MULTI_CLS_WORDS   8u
+#define KMP_MULTI_CLS_SHIFT   7u       /* class of a bucket in a classed group: bucket >> this */
+#define KMP_MULTI_CLS_WORD(n_short, first_rec, first_id) ((uint32_t)(n_short) | ((uint32_t)(first_rec) << 9) | ((uint32_t)(first_id) << 20))
 #define KMP_MULTI_REC_WORDS   2u
 #define KMP_MULTI_MAX_UNIQUE  256u       /* unique patterns of a plain group; a classed one: four times as many */
 #define KMP_MULTI_MAX_UNITS   256u     /* work units a block's region is cut into at most (their entries sit in LDS, 16 bytes each) */

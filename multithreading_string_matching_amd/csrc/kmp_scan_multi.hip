@@ -263,21 +263,21 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             }
         };
         /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first};
-         * cls: the bucket's class (0 in a plain group), cw: that class's word {its short patterns, its first record << 16} */
-        auto walk = [&](uint32_t T0, uint32_t T1, uint32_t room, uint32_t pos, uint2 bk, uint32_t cls, uint32_t cw, bool act) {
+         * cw: the word of the bucket's class (KMP_MULTI_CLS_WORD: its short patterns, its first record, its first id) */
+        auto walk = [&](uint32_t T0, uint32_t T1, uint32_t room, uint32_t pos, uint2 bk, uint32_t cw, bool act) {
             uint32_t ent = bk.x;
             uint32_t e = bk.y & 0xFFFFu;
             uint32_t n = act ? (bk.y >> 16) : 0u;                   /* entries left, this one included; a false hit of the filter usually finds an empty bucket */
             while (ballot64(n != 0u) != 0ull) {
                 /* first three bytes (two for a 2-byte pattern: its third byte is 0x00 and skipped) */
                 const bool m3 = n != 0u && __builtin_amdgcn_msad_u8(T0, ent & 0x00FFFFFFu, 0u) == 0u;
-                const uint32_t uid_lo = ent >> 24, uid = uid_lo | (cls << 8);
-                const bool lng = uid_lo >= (cw & 0xFFFFu);
+                const uint32_t uid_lo = ent >> 24, uid = (cw >> 20) + uid_lo;
+                const bool lng = uid_lo >= (cw & 0x1FFu);
                 bool hit = m3 && !lng && ((ent & 0x00FF0000u) ? 3u : 2u) <= room;
                 if (ballot64(m3 && lng) != 0ull) {
                     /* rare: the first three bytes of a pattern of four bytes or more */
                     if (m3 && lng) {
-                        const uint2 rec = *reinterpret_cast<const uint2 *>(s_rec + KMP_MULTI_CLS_WORDS + ((cw >> 16) + uid_lo - (cw & 0xFFFFu)) * KMP_MULTI_REC_WORDS);
+                        const uint2 rec = *reinterpret_cast<const uint2 *>(s_rec + KMP_MULTI_CLS_WORDS + (((cw >> 9) & 0x7FFu) + uid_lo - (cw & 0x1FFu)) * KMP_MULTI_REC_WORDS);
                         const uint32_t m = (rec.x >> 8) & 0xFFu;
                         const uint32_t m47 = m >= 8u ? 0xFFFFFFFFu : m > 4u ? (1u << (8u * (m - 4u))) - 1u : 0u;      /* which of the bytes 4-7 the pattern has */
                         const bool eight = (T0 >> 24) == (rec.x & 0xFFu) && ((T1 ^ rec.y) & m47) == 0u && m <= room;
@@ -335,8 +335,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             const uint32_t T1 = __builtin_amdgcn_alignbyte(x2, x1, i);
             const uint32_t hx = (uint32_t)__umul24(T0 & bmask, KMP_MULTI_MUL) >> 22;                                           /* KMP_MULTI_HASH */
             const uint2 bk = reinterpret_cast<const uint2 *>(s_bucket)[hx];
-            const uint32_t cls = hx >> cshift;                                      /* (a plain group: 0) */
-            const uint32_t cw = s_rec[cls];
+            const uint32_t cw = s_rec[hx >> cshift];                                /* the bucket's class (a plain group has one) */
             q_head = ring_wrap(q_head + nproc);
             q_count -= nproc;
             const uint64_t again = ballot64(rest != 0u);
@@ -350,7 +349,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                 }
                 q_count += (uint32_t)__builtin_popcountll(again);
             }
-            walk(T0, T1, rem > i ? rem - i : 0u, r1.w + i, bk, cls, cw, act);
+            walk(T0, T1, rem > i ? rem - i : 0u, r1.w + i, bk, cw, act);
         };
 
         for (;;) {

@@ -544,7 +544,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
     uint32_t n_long = c->n_long, n_short = c->n_short;
     size_t part_base = 0;                         /* partial rows already used */
     if (do_fused) {
-        /* one read of the arena for every group of (at most 256) unique patterns of 2..20 bytes */
+        /* one read of the arena for every group of unique patterns of 2..99 bytes (up to 256, classed groups up to 1024) */
         uint32_t max_u = 0;
         for (const kmpgpu_ctx::FusedGroup &g : c->fused_groups) {
             kmp_scan_args f = a;
@@ -788,10 +788,11 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     if (c->d_rest_ids) { HIP_TRY(hipFree(c->d_rest_ids)); c->d_rest_ids = nullptr; }
     c->rest_long = c->rest_short = 0;
     /* a group: its distinct patterns, the row (unique-pattern id of the kernel) of each, the patterns counted by it and their rows.
-     * `classed`: more than 256 rows -- the kernel takes the upper two bits of an id from the bucket's number (the entry has eight),
-     * so the patterns whose key hashes into bucket class c (= bucket >> 8) are numbered 256 c .. 256 c + 255 (kmp_device.h) */
+     * `classed`: more than 256 rows -- an entry has eight bits for an id, the kernel adds the first id of the bucket's class
+     * (= bucket >> 7: eight classes of up to 256 patterns each, 1024 in all; kmp_device.h) */
+    constexpr uint32_t NCLS = KMP_MULTI_CLS_WORDS;
     struct HostGroup { std::vector<std::string> uniq; std::vector<uint32_t> row; std::vector<uint32_t> ids, rows; bool classed = false;
-                       uint32_t n_cls[4] = {0, 0, 0, 0}, n_cls_short[4] = {0, 0, 0, 0}, overflow = 0; std::vector<uint8_t> bucket_used; };
+                       uint32_t n_cls[NCLS] = {}, overflow = 0; std::vector<uint8_t> bucket_used; };
     std::vector<HostGroup> hg;
     std::vector<uint32_t> rest_l, rest_s;
     /* 1-byte patterns: up to KMP_MULTI_MAX_ONES distinct ones ride along with the first fused group (counted straight
@@ -821,7 +822,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     /* Which group a distinct pattern goes to.  Up to 256 of them: one group, rows in file order (short ones first, below).  More: the
      * 2-byte patterns (entered under every third byte: 32 buckets each, in all classes) and, if 1-byte patterns ride along, the first
      * patterns of the file fill plain groups of 256; everything else goes to classed groups of up to 1024 -- first fit, a pattern
-     * whose class is full (256 per class, 255 short ones) or whose bucket would overflow the entry list waits for the next group. */
+     * whose class is full (256) or whose bucket would overflow the entry list waits for the next group. */
     std::vector<std::pair<uint32_t, uint32_t>> place(uniq_all.size());        /* distinct pattern -> (group, index in its uniq) */
     auto key_class = [](const std::string &p) {
         const uint32_t w24 = (uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | ((uint32_t)(uint8_t)p[2] << 16);
@@ -844,16 +845,15 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         const size_t first_classed = hg.size();
         for (uint32_t u : classed) {
             const std::string &p = uniq_all[u];
-            const uint32_t b = key_class(p), cl = b >> 8;
-            const bool shortp = p.size() <= KMP_MULTI_SHORT_LEN;
+            const uint32_t b = key_class(p), cl = b >> KMP_MULTI_CLS_SHIFT;
             size_t gi = first_classed;
             for (; gi < hg.size(); gi++) {
                 HostGroup &h = hg[gi];
-                if (h.n_cls[cl] < 256u && (!shortp || h.n_cls_short[cl] < 255u) && h.overflow + (h.bucket_used[b] ? 1u : 0u) <= KMP_MULTI_MAX_ENTRIES) break;
+                if (h.uniq.size() < 4u * KMP_MULTI_MAX_UNIQUE && h.n_cls[cl] < 256u && h.overflow + (h.bucket_used[b] ? 1u : 0u) <= KMP_MULTI_MAX_ENTRIES) break;
             }
             if (gi == hg.size()) { hg.emplace_back(); hg.back().classed = true; hg.back().bucket_used.assign(KMP_MULTI_BUCKETS, 0); }
             HostGroup &h = hg[gi];
-            h.n_cls[cl]++; if (shortp) h.n_cls_short[cl]++;
+            h.n_cls[cl]++;
             if (h.bucket_used[b]) h.overflow++; else h.bucket_used[b] = 1;
             place[u] = {(uint32_t)gi, (uint32_t)h.uniq.size()};
             h.uniq.push_back(p);
@@ -866,28 +866,32 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         uint32_t ones = 0;
         for (uint32_t k = 0; k < n_ones; k++) ones |= (uint32_t)one_bytes[k] << (8 * k);
         first_group = false;
-        /* rows: short patterns (2 or 3 bytes: decided by their bucket entry alone) first -- in the whole group, or in every class */
-        uint32_t cls_short[4] = {0, 0, 0, 0}, cls_n[4] = {0, 0, 0, 0}, rec_base[4] = {0, 0, 0, 0}, rows_n = 0;
-        std::vector<uint32_t> cls_of(U, 0u);
+        /* rows: class by class, short patterns (2 or 3 bytes: decided by their bucket entry alone) first in each (a plain group is one class) */
+        uint32_t cls_short[NCLS] = {}, cls_n[NCLS] = {}, rec_base[NCLS] = {}, row_base[NCLS] = {};
+        std::vector<uint32_t> cls_of(U, 0u), in_cls(U, 0u);
         h.row.assign(U, 0u);
         for (uint32_t u = 0; u < U; u++) {
-            cls_of[u] = h.classed ? key_class(h.uniq[u]) >> 8 : 0u;
+            cls_of[u] = h.classed ? key_class(h.uniq[u]) >> KMP_MULTI_CLS_SHIFT : 0u;
+            cls_n[cls_of[u]]++;
             if (h.uniq[u].size() <= KMP_MULTI_SHORT_LEN) cls_short[cls_of[u]]++;
         }
+        for (uint32_t cl = 1; cl < NCLS; cl++) {
+            row_base[cl] = row_base[cl - 1] + cls_n[cl - 1];
+            rec_base[cl] = rec_base[cl - 1] + (cls_n[cl - 1] - cls_short[cl - 1]);
+        }
         {
-            uint32_t next_short[4] = {0, 0, 0, 0}, next_long[4] = {cls_short[0], cls_short[1], cls_short[2], cls_short[3]};
+            uint32_t next_short[NCLS] = {}, next_long[NCLS];
+            for (uint32_t cl = 0; cl < NCLS; cl++) next_long[cl] = cls_short[cl];
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t cl = cls_of[u];
-                const uint32_t in = h.uniq[u].size() <= KMP_MULTI_SHORT_LEN ? next_short[cl]++ : next_long[cl]++;
-                h.row[u] = cl * 256u + in;
-                cls_n[cl] = std::max(cls_n[cl], in + 1u);
-                rows_n = std::max(rows_n, h.row[u] + 1u);
+                in_cls[u] = h.uniq[u].size() <= KMP_MULTI_SHORT_LEN ? next_short[cl]++ : next_long[cl]++;
+                h.row[u] = row_base[cl] + in_cls[u];
             }
-            for (uint32_t cl = 1; cl < 4; cl++) rec_base[cl] = rec_base[cl - 1] + (cls_n[cl - 1] - cls_short[cl - 1]);
         }
-        const uint32_t n_long = rec_base[3] + (cls_n[3] - cls_short[3]);
+        const uint32_t rows_n = U;
+        const uint32_t n_long = rec_base[NCLS - 1] + (cls_n[NCLS - 1] - cls_short[NCLS - 1]);
         std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)n_long * KMP_MULTI_REC_WORDS, 0u);
-        for (uint32_t cl = 0; cl < 4; cl++) tab[KMP_MULTI_REC_W0 + cl] = cls_short[cl] | (rec_base[cl] << 16);
+        for (uint32_t cl = 0; cl < NCLS; cl++) tab[KMP_MULTI_REC_W0 + cl] = KMP_MULTI_CLS_WORD(cls_short[cl], rec_base[cl], row_base[cl]);
         uint32_t *bucket = tab.data() + KMP_MULTI_BUCKET_W0;
         uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
         std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
@@ -914,7 +918,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             }
             if (p.size() <= KMP_MULTI_SHORT_LEN) continue;
             const uint32_t cl = cls_of[u];
-            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)(rec_base[cl] + (h.row[u] & 255u) - cls_short[cl]) * KMP_MULTI_REC_WORDS;
+            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)(rec_base[cl] + in_cls[u] - cls_short[cl]) * KMP_MULTI_REC_WORDS;
             rec[0] = (uint32_t)(uint8_t)p[3] | ((uint32_t)p.size() << 8);          /* byte 3 (the entry has bytes 0-2), the length */
             for (uint32_t b = 4; b < p.size() && b < 8u; b++) rec[1] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
         }
@@ -924,7 +928,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
                 const uint32_t u = lists[hh][q];
                 const std::string &p = h.uniq[u];
                 const uint32_t third = p.size() >= 3 ? (uint32_t)(uint8_t)p[2] : 0u;      /* never 0x00 inside a pattern */
-                const uint32_t ent = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | (third << 16) | ((h.row[u] & 255u) << 24);
+                const uint32_t ent = (uint32_t)(uint8_t)p[0] | ((uint32_t)(uint8_t)p[1] << 8) | (third << 16) | (in_cls[u] << 24);
                 if (q == 0) { bucket[2 * hh] = ent; continue; }       /* the first entry sits in the bucket itself */
                 if (pos >= KMP_MULTI_MAX_ENTRIES) return fail(KMPGPU_EINVAL, "kmpgpu_set_patterns: fused tables: entry list overflow");
                 entry[pos++] = ent;
@@ -961,7 +965,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         HIP_TRY(up(&g.d_rows, h.rows));
         HIP_TRY(up(&g.d_uid_first, uid_first));
         HIP_TRY(up(&g.d_uid_ids, uid_ids));
-        g.words = (uint32_t)tab.size(); g.n_unique = rows_n + n_ones; g.cshift = h.classed ? 8u : 10u; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
+        g.words = (uint32_t)tab.size(); g.n_unique = rows_n + n_ones; g.cshift = h.classed ? KMP_MULTI_CLS_SHIFT : 10u; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
         c->n_multi_unique += U;
     }
     std::vector<uint32_t> rest(rest_l);
