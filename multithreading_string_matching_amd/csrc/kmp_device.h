@@ -52,10 +52,13 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
  *                    (c0, c1).  No hash: letters of one case never share a bit, text gives no false hit (round 2's first
  *                    filter, 16384 hashed slots: 42 % of its hits on lower-case text were collisions).  The factor 33
  *                    spreads the entries over the bank pairs by c1 + c2 (one letter alone covers 26 of 32).
- *   [4672, 4680)     one word per bucket class, KMP_MULTI_CLS_WORD: its short patterns | its first record << 9 | its first id << 20
- *   [4680, ...)      one 2-word record per LONG unique pattern (4+ bytes; record = first of its class + the entry's eight
- *                    bits - the class's short ones): byte 3 | m << 8, bytes 4-7 (a pattern of nine bytes or more compares its rest
- *                    against kmp_pattern_dev[].pat of the first pattern that has this id, uid_ids[uid_first[id]])
+ *   [4672, ...)      a plain group: one 4-word record per LONG unique pattern (4+ bytes; record = id - n_short): bytes 0-3, bytes 4-7,
+ *                    the byte mask of bytes 4-7, m | pattern index << 8 (a pattern of nine bytes or more compares its
+ *                    rest against kmp_pattern_dev[index].pat);
+ *                    a classed group: [4672, 4680) one word per bucket class, KMP_MULTI_CLS_WORD: its short patterns | its
+ *                    first record << 9 | its first id << 20, then one 2-word record per long pattern (record = first of its
+ *                    class + the entry's eight bits - the class's short ones): byte 3 | m << 8 | pattern index << 16, bytes 4-7
+ *                    (1024 records of 16 bytes would not leave room for two blocks per CU)
  * The first 4672 words live in static LDS (their offsets fold into the ds_read offset field). */
 #define KMP_MULTI_BUCKETS     1024u
 #define KMP_MULTI_BUCKET_W0   0u
@@ -69,7 +72,8 @@ typedef struct __attribute__((aligned(16))) kmp_pattern_dev {
 #define KMP_MULTI_CLS_WORDS   8u
 #define KMP_MULTI_CLS_SHIFT   7u       /* class of a bucket in a classed group: bucket >> this */
 #define KMP_MULTI_CLS_WORD(n_short, first_rec, first_id) ((uint32_t)(n_short) | ((uint32_t)(first_rec) << 9) | ((uint32_t)(first_id) << 20))
-#define KMP_MULTI_REC_WORDS   2u
+#define KMP_MULTI_REC_WORDS   4u
+#define KMP_MULTI_CREC_WORDS  2u
 #define KMP_MULTI_MAX_UNIQUE  256u       /* unique patterns of a plain group; a classed one: four times as many */
 #define KMP_MULTI_MAX_UNITS   256u     /* work units a block's region is cut into at most (their entries sit in LDS, 16 bytes each) */
 #define KMP_MULTI_MIN_LEN     2u

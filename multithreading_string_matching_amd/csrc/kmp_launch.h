@@ -32,6 +32,7 @@ struct kmp_scan_args {
     /* fused pass only: the arena in `fused_blocks` regions of `units_per_block` work units each (kmp_plan_shape) */
     uint32_t               fused_blocks, units_per_block, n_units;   /* units_per_block: per REGION, which fused_sides (1 or 2) blocks share */
     uint32_t               fused_sides;
+    bool                   fused_classed; /* the group of this launch is a classed one (kmp_device.h): cshift is a shift; a plain group: its short patterns */
     uint32_t              *fused_pool;   /* [regions] next unit of the region's pool, all 0 before the launch */
     uint64_t               span_end;     /* end of the last slot                                        */
     bool                   pad_clean;    /* every byte between a payload's end and the next slot is 0x00 */

@@ -80,7 +80,7 @@ __device__ __forceinline__ void shr_by_byte_into(uint32_t &acc, uint32_t word, u
 #undef KMP_SHR_SDWA
 }
 
-template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES, uint32_t WAVES>
+template <int DEPTH, bool NT, bool CLEAN, bool EMIT, bool ONES, uint32_t WAVES, bool CLASSED>
 __device__ __forceinline__ void
 kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restrict__ pkt_len,
                       const unsigned long long *__restrict__ bitmap, const kmp_plan_entry *__restrict__ plan,
@@ -263,7 +263,8 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             }
         };
         /* the patterns of one bucket against the eight text bytes T0, T1 of a hit: bk = {first entry, further entries: count << 16 | first};
-         * cw: the word of the bucket's class (KMP_MULTI_CLS_WORD: its short patterns, its first record, its first id) */
+         * cw (a classed group, kmp_device.h): the word of the bucket's class -- KMP_MULTI_CLS_WORD: its short patterns, its first record,
+         * its first id; a plain group: the number of its short patterns (the kernel's cshift argument is that number there) */
         auto walk = [&](uint32_t T0, uint32_t T1, uint32_t room, uint32_t pos, uint2 bk, uint32_t cw, bool act) {
             uint32_t ent = bk.x;
             uint32_t e = bk.y & 0xFFFFu;
@@ -271,16 +272,26 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             while (ballot64(n != 0u) != 0ull) {
                 /* first three bytes (two for a 2-byte pattern: its third byte is 0x00 and skipped) */
                 const bool m3 = n != 0u && __builtin_amdgcn_msad_u8(T0, ent & 0x00FFFFFFu, 0u) == 0u;
-                const uint32_t uid_lo = ent >> 24, uid = (cw >> 20) + uid_lo;
-                const bool lng = uid_lo >= (cw & 0x1FFu);
+                const uint32_t uid_lo = ent >> 24, uid = CLASSED ? (cw >> 20) + uid_lo : uid_lo;
+                const bool lng = uid_lo >= (CLASSED ? cw & 0x1FFu : cw);
                 bool hit = m3 && !lng && ((ent & 0x00FF0000u) ? 3u : 2u) <= room;
                 if (ballot64(m3 && lng) != 0ull) {
                     /* rare: the first three bytes of a pattern of four bytes or more */
                     if (m3 && lng) {
-                        const uint2 rec = *reinterpret_cast<const uint2 *>(s_rec + KMP_MULTI_CLS_WORDS + (((cw >> 9) & 0x7FFu) + uid_lo - (cw & 0x1FFu)) * KMP_MULTI_REC_WORDS);
-                        const uint32_t m = (rec.x >> 8) & 0xFFu;
-                        const uint32_t m47 = m >= 8u ? 0xFFFFFFFFu : m > 4u ? (1u << (8u * (m - 4u))) - 1u : 0u;      /* which of the bytes 4-7 the pattern has */
-                        const bool eight = (T0 >> 24) == (rec.x & 0xFFu) && ((T1 ^ rec.y) & m47) == 0u && m <= room;
+                        uint32_t m, pidx;
+                        bool eight;
+                        if constexpr (CLASSED) {
+                            const uint2 rec = *reinterpret_cast<const uint2 *>(s_rec + KMP_MULTI_CLS_WORDS + (((cw >> 9) & 0x7FFu) + uid_lo - (cw & 0x1FFu)) * KMP_MULTI_CREC_WORDS);
+                            m = (rec.x >> 8) & 0xFFu;
+                            pidx = rec.x >> 16;
+                            const uint32_t m47 = m >= 8u ? 0xFFFFFFFFu : m > 4u ? (1u << (8u * (m - 4u))) - 1u : 0u;      /* which of the bytes 4-7 the pattern has */
+                            eight = (T0 >> 24) == (rec.x & 0xFFu) && ((T1 ^ rec.y) & m47) == 0u && m <= room;
+                        } else {
+                            const uint4 rec = *reinterpret_cast<const uint4 *>(s_rec + (uid - cw) * KMP_MULTI_REC_WORDS);
+                            m = rec.w & 0xFFu;
+                            pidx = rec.w >> 8;
+                            eight = T0 == rec.x && ((T1 ^ rec.y) & rec.z) == 0u && m <= room;
+                        }
                         hit = eight && m <= 8u;
                         if (eight && m > 8u) {
                             /* rarer: nine bytes or more, the first eight match: the rest straight from the arena (a 0x00 of
@@ -299,7 +310,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                             }
                             if (ok) {
                                 const uint8_t *tp = reinterpret_cast<const uint8_t *>((uint64_t)(uint32_t)rsrc.x | ((uint64_t)(uint32_t)rsrc.y << 32)) + pos;
-                                const uint8_t *pp = patterns[uid_ids[uid_first[uid]]].pat;      /* (the first pattern that has this id) */
+                                const uint8_t *pp = patterns[pidx].pat;
                                 for (uint32_t b = 8u; b < m; ++b)
                                     if (tp[b] != pp[b]) { ok = false; break; }
                             }
@@ -335,7 +346,7 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
             const uint32_t T1 = __builtin_amdgcn_alignbyte(x2, x1, i);
             const uint32_t hx = (uint32_t)__umul24(T0 & bmask, KMP_MULTI_MUL) >> 22;                                           /* KMP_MULTI_HASH */
             const uint2 bk = reinterpret_cast<const uint2 *>(s_bucket)[hx];
-            const uint32_t cw = s_rec[hx >> cshift];                                /* the bucket's class (a plain group has one) */
+            const uint32_t cw = CLASSED ? s_rec[hx >> cshift] : cshift;             /* the bucket's class */
             q_head = ring_wrap(q_head + nproc);
             q_count -= nproc;
             const uint64_t again = ballot64(rest != 0u);
@@ -717,25 +728,25 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                          const uint32_t *__restrict__ uid_ids, const kmp_pattern_dev *__restrict__ patterns
 #define KMP_MULTI_ARGS arena, pkt_len, bitmap, plan, tables, table_words, n_unique, cshift, bmask, n_ones, ones, ablate, n_units, upb, sides, pool_next, span_end, pstride, partials, em, uid_first, uid_ids, patterns
 
-template <int DEPTH, bool NT, bool CLEAN, bool ONES>
+template <int DEPTH, bool NT, bool CLEAN, bool ONES, bool CLASSED>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 kmp_scan_multi_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES, KMP_MULTI_BLOCK_WAVES>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES, KMP_MULTI_BLOCK_WAVES, CLASSED>(KMP_MULTI_ARGS);
 }
 
-template <int DEPTH, bool NT, bool CLEAN, bool ONES>
+template <int DEPTH, bool NT, bool CLEAN, bool ONES, bool CLASSED>
 __global__ void __launch_bounds__(KMP_MULTI_WIDE_WAVES * KMP_WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 kmp_scan_multi_wide_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES, KMP_MULTI_WIDE_WAVES>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, false, ONES, KMP_MULTI_WIDE_WAVES, CLASSED>(KMP_MULTI_ARGS);
 }
 
-template <int DEPTH, bool NT, bool CLEAN, bool ONES>
+template <int DEPTH, bool NT, bool CLEAN, bool ONES, bool CLASSED>
 __global__ void __launch_bounds__(KMP_MULTI_BLOCK_THREADS)
 kmp_scan_multi_emit_kernel(KMP_MULTI_PARAMS)
 {
-    kmp_scan_multi_body<DEPTH, NT, CLEAN, true, ONES, KMP_MULTI_BLOCK_WAVES>(KMP_MULTI_ARGS);
+    kmp_scan_multi_body<DEPTH, NT, CLEAN, true, ONES, KMP_MULTI_BLOCK_WAVES, CLASSED>(KMP_MULTI_ARGS);
 }
 
 }  // namespace
@@ -774,6 +785,7 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     const kmp_plan_entry *plan = reinterpret_cast<const kmp_plan_entry *>(a.plan);
     const int kind = kmp_multi_kind(a.emit_out != nullptr, a.pad_clean, n_ones);
     const uint32_t bwaves = kmp_multi_block_waves(kind);
+    const bool classed = a.fused_classed;
     const size_t lds = kmp_multi_lds_bytes(table_words, n_unique, bwaves) - KMP_MULTI_STATIC_BYTES;      /* the dynamic part */
     const Emitter em{reinterpret_cast<uint4 *>(a.emit_out), a.emit_counter, a.emit_cap, 0u};
     /* tuning builds only (make HIPFLAGS+=-DKMP_MULTI_TUNING; tools/fused_ablation.py, profiles/r02_fused_ablation.txt): cut the
@@ -784,11 +796,16 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
 #else
     const uint32_t ablate = 0u;
 #endif
-#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_>), dim3(a.fused_blocks), \
+#define KMP_MULTI_LAUNCH1(KERNEL_, NT_, CLEAN_, ONES_) KMP_MULTI_LAUNCH0(KERNEL_, NT_, CLEAN_, ONES_, false)
+#define KMP_MULTI_LAUNCH0(KERNEL_, NT_, CLEAN_, ONES_, CLASSED_) hipLaunchKernelGGL((KERNEL_<3, NT_, CLEAN_, ONES_, CLASSED_>), dim3(a.fused_blocks), \
         dim3(bwaves * KMP_WAVE), lds, st, a.arena, a.pkt_len, a.bitmap, plan, tables, table_words, n_unique, cshift, bucket_mask, n_ones, ones, ablate, a.n_units, a.units_per_block, a.fused_sides, a.fused_pool, a.span_end, a.blocks_x, \
         a.partials, em, uid_first, uid_ids, a.patterns)
 #define KMP_MULTI_LAUNCH(EMIT_K_, NT_, CLEAN_) do {                                                                               \
-        if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \
+        if (classed) {        /* (a classed group has no 1-byte patterns riding along) */                                             \
+            if (EMIT_K_) KMP_MULTI_LAUNCH0(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false, true);                                     \
+            else if (!(CLEAN_)) KMP_MULTI_LAUNCH0(kmp_scan_multi_wide_kernel, NT_, CLEAN_, false, true);                              \
+            else KMP_MULTI_LAUNCH0(kmp_scan_multi_kernel, NT_, true, false, true);                                                    \
+        } else if (EMIT_K_) { if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, true); else KMP_MULTI_LAUNCH1(kmp_scan_multi_emit_kernel, NT_, CLEAN_, false); } \
         else if (n_ones) KMP_MULTI_LAUNCH1(kmp_scan_multi_wide_kernel, NT_, CLEAN_, true);                                           \
         else if (!(CLEAN_)) KMP_MULTI_LAUNCH1(kmp_scan_multi_wide_kernel, NT_, CLEAN_, false);                                       \
         else KMP_MULTI_LAUNCH1(kmp_scan_multi_kernel, NT_, true, false); } while (0)
@@ -797,5 +814,6 @@ hipError_t kmp_launch_scan_multi(const kmp_scan_args &a, const uint32_t *tables,
     else                  { if (a.nontemporal) KMP_MULTI_LAUNCH(false, true, false); else KMP_MULTI_LAUNCH(false, false, false); }
 #undef KMP_MULTI_LAUNCH
 #undef KMP_MULTI_LAUNCH1
+#undef KMP_MULTI_LAUNCH0
     return hipGetLastError();
 }

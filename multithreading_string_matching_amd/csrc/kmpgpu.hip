@@ -79,7 +79,8 @@ struct kmpgpu_ctx {
         uint32_t *d_ids = nullptr;           /* [n_ids] pattern indices counted by this group            */
         uint32_t *d_rows = nullptr;          /* [n_ids] their unique-pattern row                         */
         uint32_t *d_uid_first = nullptr, *d_uid_ids = nullptr;   /* row -> pattern indices (offset emission): CSR */
-        uint32_t  words = 0, n_unique = 0, cshift = 10, bmask = 0, n_ones = 0, ones = 0, n_ids = 0;
+        uint32_t  words = 0, n_unique = 0, cshift = 0, bmask = 0, n_ones = 0, ones = 0, n_ids = 0;   /* cshift: a plain group's short patterns, a classed one's class shift */
+        bool      classed = false;
     };
     std::vector<FusedGroup> fused_groups;
     uint32_t              n_multi_unique = 0;          /* distinct eligible patterns over all groups */
@@ -550,6 +551,7 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             kmp_scan_args f = a;
             f.arena = c->d_arena;
             f.plan = c->d_uplan;
+            f.fused_classed = g.classed;
             f.partials = c->d_partials;
             if (a.units_per_block > a.fused_sides * kmp_multi_block_waves(kmp_multi_kind(emit != nullptr, c->pad_clean, g.n_ones)))      /* (regions without a pool: nobody asks the counters) */
                 HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));      /* the regions' pool counters */
@@ -791,7 +793,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
      * `classed`: more than 256 rows -- an entry has eight bits for an id, the kernel adds the first id of the bucket's class
      * (= bucket >> 7: eight classes of up to 256 patterns each, 1024 in all; kmp_device.h) */
     constexpr uint32_t NCLS = KMP_MULTI_CLS_WORDS;
-    struct HostGroup { std::vector<std::string> uniq; std::vector<uint32_t> row; std::vector<uint32_t> ids, rows; bool classed = false;
+    struct HostGroup { std::vector<std::string> uniq; std::vector<uint32_t> gidx, row; std::vector<uint32_t> ids, rows; bool classed = false;
                        uint32_t n_cls[NCLS] = {}, overflow = 0; std::vector<uint8_t> bucket_used; };
     std::vector<HostGroup> hg;
     std::vector<uint32_t> rest_l, rest_s;
@@ -800,6 +802,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
     std::vector<uint8_t> one_bytes;
     std::vector<std::pair<uint32_t, uint32_t>> one_ids;            /* (pattern index, slot) */
     std::vector<std::string> uniq_all;                             /* the distinct eligible patterns, file order */
+    std::vector<uint32_t> first_pat;                               /* ... and the first pattern of the list that is each of them */
     std::unordered_map<std::string, uint32_t> uniq_of;
     std::vector<std::pair<uint32_t, uint32_t>> elig;               /* (pattern index, its distinct pattern) */
     for (uint32_t i = 0; i < n_pat; i++) {
@@ -813,7 +816,12 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         if (m < KMP_MULTI_MIN_LEN || m > KMP_MULTI_MAX_LEN) { (m >= 4 ? rest_l : rest_s).push_back(i); continue; }
         const std::string key((const char *)pat[i], m);
         auto it = uniq_of.find(key);
-        if (it == uniq_of.end()) { it = uniq_of.emplace(key, (uint32_t)uniq_all.size()).first; uniq_all.push_back(key); }
+        if (it == uniq_of.end()) {
+            /* (a record names the pattern whose bytes 8 .. m-1 the kernel compares against in 16 bits: a pattern of nine bytes or
+             * more that first occurs behind the 65 536th of the list keeps a pass of its own) */
+            if (m > 8 && i > 0xFFFFu) { rest_l.push_back(i); continue; }
+            it = uniq_of.emplace(key, (uint32_t)uniq_all.size()).first; uniq_all.push_back(key); first_pat.push_back(i);
+        }
         elig.emplace_back(i, it->second);
     }
     if (uniq_all.size() < 2) {                    /* nothing to fuse: every pattern keeps its own pass (c->d_ids) */
@@ -840,7 +848,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         for (uint32_t u : plain) {
             if (hg.empty() || hg.back().uniq.size() == KMP_MULTI_MAX_UNIQUE) hg.emplace_back();
             place[u] = {(uint32_t)hg.size() - 1u, (uint32_t)hg.back().uniq.size()};
-            hg.back().uniq.push_back(uniq_all[u]);
+            hg.back().uniq.push_back(uniq_all[u]); hg.back().gidx.push_back(u);
         }
         const size_t first_classed = hg.size();
         for (uint32_t u : classed) {
@@ -856,7 +864,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             h.n_cls[cl]++;
             if (h.bucket_used[b]) h.overflow++; else h.bucket_used[b] = 1;
             place[u] = {(uint32_t)gi, (uint32_t)h.uniq.size()};
-            h.uniq.push_back(p);
+            h.uniq.push_back(p); h.gidx.push_back(u);
         }
     }
     bool first_group = true;
@@ -890,8 +898,9 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         }
         const uint32_t rows_n = U;
         const uint32_t n_long = rec_base[NCLS - 1] + (cls_n[NCLS - 1] - cls_short[NCLS - 1]);
-        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)n_long * KMP_MULTI_REC_WORDS, 0u);
-        for (uint32_t cl = 0; cl < NCLS; cl++) tab[KMP_MULTI_REC_W0 + cl] = KMP_MULTI_CLS_WORD(cls_short[cl], rec_base[cl], row_base[cl]);
+        std::vector<uint32_t> tab(KMP_MULTI_REC_W0 + (h.classed ? KMP_MULTI_CLS_WORDS + (size_t)n_long * KMP_MULTI_CREC_WORDS : (size_t)n_long * KMP_MULTI_REC_WORDS), 0u);
+        if (h.classed)
+            for (uint32_t cl = 0; cl < NCLS; cl++) tab[KMP_MULTI_REC_W0 + cl] = KMP_MULTI_CLS_WORD(cls_short[cl], rec_base[cl], row_base[cl]);
         uint32_t *bucket = tab.data() + KMP_MULTI_BUCKET_W0;
         uint32_t *entry = tab.data() + KMP_MULTI_ENTRY_W0;
         std::vector<std::vector<uint32_t>> lists(KMP_MULTI_BUCKETS);
@@ -918,9 +927,18 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
             }
             if (p.size() <= KMP_MULTI_SHORT_LEN) continue;
             const uint32_t cl = cls_of[u];
-            uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)(rec_base[cl] + in_cls[u] - cls_short[cl]) * KMP_MULTI_REC_WORDS;
-            rec[0] = (uint32_t)(uint8_t)p[3] | ((uint32_t)p.size() << 8);          /* byte 3 (the entry has bytes 0-2), the length */
-            for (uint32_t b = 4; b < p.size() && b < 8u; b++) rec[1] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
+            if (h.classed) {
+                uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + KMP_MULTI_CLS_WORDS + (size_t)(rec_base[cl] + in_cls[u] - cls_short[cl]) * KMP_MULTI_CREC_WORDS;
+                rec[0] = (uint32_t)(uint8_t)p[3] | ((uint32_t)p.size() << 8) | (first_pat[h.gidx[u]] << 16);      /* byte 3 (the entry has bytes 0-2), the length, a pattern that has the rest */
+                for (uint32_t b = 4; b < p.size() && b < 8u; b++) rec[1] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
+            } else {
+                uint32_t *rec = tab.data() + KMP_MULTI_REC_W0 + (size_t)(in_cls[u] - cls_short[0]) * KMP_MULTI_REC_WORDS;
+                for (uint32_t b = 0; b < p.size() && b < 8u; b++) {
+                    rec[b >> 2] |= (uint32_t)(uint8_t)p[b] << (8 * (b & 3));
+                    if (b >= 4u) rec[2] |= 0xFFu << (8 * (b & 3));
+                }
+                rec[3] = (uint32_t)p.size() | (first_pat[h.gidx[u]] << 8);         /* the rest of it: kmp_pattern_dev[that index].pat */
+            }
         }
         uint32_t pos = 0;
         for (uint32_t hh = 0; hh < KMP_MULTI_BUCKETS; hh++) {
@@ -965,7 +983,7 @@ int kmpgpu_set_patterns(kmpgpu_ctx *c, const uint8_t *const *pat, const uint32_t
         HIP_TRY(up(&g.d_rows, h.rows));
         HIP_TRY(up(&g.d_uid_first, uid_first));
         HIP_TRY(up(&g.d_uid_ids, uid_ids));
-        g.words = (uint32_t)tab.size(); g.n_unique = rows_n + n_ones; g.cshift = h.classed ? KMP_MULTI_CLS_SHIFT : 10u; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
+        g.words = (uint32_t)tab.size(); g.n_unique = rows_n + n_ones; g.cshift = h.classed ? KMP_MULTI_CLS_SHIFT : cls_short[0]; g.classed = h.classed; g.bmask = bmask; g.n_ones = n_ones; g.ones = ones; g.n_ids = (uint32_t)h.ids.size();
         c->n_multi_unique += U;
     }
     std::vector<uint32_t> rest(rest_l);
