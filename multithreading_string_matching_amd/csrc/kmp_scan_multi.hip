@@ -236,8 +236,6 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
         uint32_t last_start = 0u;            /* EMIT: byte position (from the region's first chunk) of that packet's start */
         int32_t  remc = 0;                   /* payload bytes of that packet left at the chunk's first byte     */
         bool     dead = false;
-        uint32_t j = 0u;
-        const unsigned long long *bw = bwr;
         /* EMIT only: the start bits of the chunk whose hits are in the queue (the queue is emptied after every chunk there) */
         uint64_t e_st = 0ull;
 
@@ -365,16 +363,17 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
 
         for (;;) {
         if (pos < uend) {
-            bw = bwr + (pos >> 10);                         /* one word per chunk */
+            {
+                const unsigned long long *const bw = bwr + (pos >> 10);         /* one word per chunk; positions and bwr both count from the region's first chunk */
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) hiw[s] = start_word(bw + s + 1);
-            low = start_word(bw);
+                for (int s = 0; s < DEPTH; ++s) hiw[s] = start_word(bw + s + 1);
+                low = start_word(bw);
+            }
             kcur = k0 - 1ull;
             kbase = k0 - 1ull;
             last_start = 0u;
             remc = 0;
             dead = false;
-            j = 0u;
         }
         while (pos < uend) {
             if (pos + (uint32_t)DEPTH * KMP_CHUNK >= uend) {
@@ -396,8 +395,11 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                 asm volatile("" : "+s"(st_[s]));      /* computed HERE, not sunk below the loads that follow */
             }
             __builtin_amdgcn_sched_barrier(0);
+            {
+                const unsigned long long *const bwj = bwr + (pos >> 10);      /* (the word of this round's first chunk: one address, three offsets) */
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) hiw[s] = start_word(bw + (j + (uint32_t)DEPTH + 1u + (uint32_t)s));
+                for (int s = 0; s < DEPTH; ++s) hiw[s] = start_word(bwj + (DEPTH + 1 + s));
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
@@ -667,7 +669,6 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
                 __builtin_amdgcn_sched_barrier(0);
                 flat_issue<NT>(buf[s], rsrc, vo0, pos + iob);
                 pos += KMP_CHUNK;
-                ++j;
             }
         }
         if (aux & 64u) {
