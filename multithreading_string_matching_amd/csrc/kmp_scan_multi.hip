@@ -18,8 +18,8 @@ namespace {
  * Fused multi-pattern pass: every pattern of 2..99 bytes in ONE read of a packed
  * arena -- the reference re-reads every payload once per pattern (serial.c:154, openmp_data.c:163).
  *
- * Same streaming skeleton as kmp_scan_packed_kernel (buffer-load ring, packet-start bitmap, byte-
- * balanced plan).  Per chunk:
+ * Same streaming skeleton as kmp_scan_packed_kernel (buffer-load ring, packet-start bitmap), but the
+ * wavefronts share the arena out in work units as they go (WORK UNITS, below).  Per chunk:
  *   - rem = payload bytes left from the lane's first byte (CLEAN: two lane masks off the start bitmap; otherwise a
  *     uniform loop over the packet starts of the chunk with lengths by scalar loads);
  *   - level 1: "may some pattern start here?" for the 16 start offsets of the lane, TWO offsets per LDS lookup: the text
@@ -27,7 +27,7 @@ namespace {
  *     may stand before that pair and which may follow it as the start of a pattern (kmp_device.h, pair table), so one
  *     ds_read_b64 decides the offsets at the window's first and second byte.  v_dot4_u32_u8 computes the entry's
  *     address, v_lshrrev_b32_sdwa shifts each word by its text byte, v_dot4 packs the verdicts into the hit mask.
- *     This level is VALU-bound (profiles/r02_fused_ablation.txt: the LDS was the limit until the lookups were halved);
+ *     This level is the pass (280 of 300 us, profiles/r03_fused_ablation.txt; vector ALUs 87 % busy, the LDS 63 %);
  *   - hits are not looked at here.  Every lane that has one appends ONE 32-byte record -- its 24 text bytes, its hit
  *     mask, the room up to the payload's end, its position -- to the wavefront's queue in LDS (slot = mbcnt over the
  *     ballot of those lanes: one ballot and two writes per chunk, no loop, no dependent LDS read), and whenever the
@@ -101,14 +101,13 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
     uint4    *s_q   = reinterpret_cast<uint4 *>(s_dyn + ((rec_words + n_unique + 3u) & ~3u));
     const uint32_t lane = threadIdx.x & (KMP_WAVE - 1u);
     const uint32_t wave = sgpr(threadIdx.x >> 6);
-    /* WORK UNITS.  The arena is cut into one region per block and every region into `upb` units of a few KiB (whole packets;
-     * plan[] holds first packet and byte offset of every unit, kmp_plan_kernel).  The wavefronts of a block TAKE the units of its
-     * region one after the other off a counter in LDS instead of owning a fixed 1/16 of it: the SIMD issues the instructions of
-     * its oldest wavefront first, so of eight wavefronts with the same work the first is done in 0.43 of the time the last one
-     * takes (profiles/r03_fused_timeline_static_ranges.txt: chunk loops of 79 .. 184 us by hardware wave slot), the block's slot
-     * and LDS stay taken until its last wavefront ends, and the next block cannot start.  With units every wavefront runs at
-     * whatever speed it gets until the region is used up, and they all end within one (small: the last quarter of a region is
-     * cut finer) unit of each other. */
+    /* WORK UNITS.  The arena is cut into regions and every region into `upb` units of whole packets (plan[] holds first packet and
+     * byte offset of every unit, kmp_plan_kernel): one large unit per wavefront, its own share, and a pool of units of a few tens of
+     * KiB that the wavefronts TAKE one after the other off a counter when they are through their share, instead of owning a fixed
+     * part of the arena each.  The SIMD issues the instructions of its oldest wavefront first, so of eight wavefronts with the same
+     * work the first is done in 0.43 of the time the last one takes (profiles/r03_fused_timeline_static_ranges.txt: chunk loops of
+     * 79 .. 184 us by hardware wave slot), the block's slot and LDS stay taken until its last wavefront ends.  With units every
+     * wavefront runs at whatever speed it gets until the region is used up, and they all end within one pool unit of each other. */
     /* Regions go by PAIRS of blocks (sides == 2; a grid of one block: 1): blocks p and p + pairs share region p.  Its first units are
      * the wavefronts' own shares -- 16 for the one block, 16 for the other --, the rest is the pool both take from, off a counter in
      * global memory.  The hardware starts one block on every CU before it starts a second one anywhere, and the SIMDs serve
