@@ -172,9 +172,10 @@ kmp_scan_multi_body(const uint8_t *__restrict__ arena, const uint32_t *__restric
      * finds an entry that says so): where its first chunk is.  (The returning atomic is a vector memory instruction: the compiler
      * waits for it with vmcnt(0), which the ring's loads -- the last chunks of the unit that is ending -- reach as well.) */
     auto claim = [&]() {
-        uint32_t t = 0u;
-        if (lane == 0u) t = __hip_atomic_fetch_add(pool_next + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t un = min(n_own + sgpr(t), KMP_MULTI_MAX_UNITS - 1u);
+        uint32_t t = KMP_MULTI_MAX_UNITS;
+        if (pool_next != nullptr && lane == 0u)          /* (regions without a pool: no counter, nobody resets one) */
+            t = __hip_atomic_fetch_add(pool_next + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t un = min(n_own + min(sgpr(t), KMP_MULTI_MAX_UNITS), KMP_MULTI_MAX_UNITS - 1u);
         aux = (aux & 63u) | 64u | (un << 8);
         const uint4 e = s_unit[un];
         return ((int32_t)sgpr(e.z) >= 0 && sgpr(e.y) != 0u) ? sgpr(e.x) : KMP_NOWHERE;

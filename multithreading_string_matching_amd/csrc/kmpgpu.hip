@@ -553,8 +553,13 @@ int enqueue_pass(kmpgpu_ctx *c, uint32_t *launches, unsigned long long *d_out, c
             f.plan = c->d_uplan;
             f.fused_classed = g.classed;
             f.partials = c->d_partials;
-            if (a.units_per_block > a.fused_sides * kmp_multi_block_waves(kmp_multi_kind(emit != nullptr, c->pad_clean, g.n_ones)))      /* (regions without a pool: nobody asks the counters) */
-                HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));      /* the regions' pool counters */
+            /* the regions' pool counters start from 0; regions without a pool (every unit is some wavefront's own) get no counter at all --
+             * one that is never reset would come round after 2^32 takes, and a streamed capture is a pass per batch */
+            f.fused_pool = nullptr;
+            if (a.units_per_block > a.fused_sides * kmp_multi_block_waves(kmp_multi_kind(emit != nullptr, c->pad_clean, g.n_ones))) {
+                HIP_TRY(hipMemsetAsync(c->d_pool, 0, (size_t)(a.fused_blocks / a.fused_sides) * sizeof(uint32_t), c->stream));
+                f.fused_pool = c->d_pool;
+            }
             hipEvent_t e0, e1;
             HIP_TRY(record(e0, e1));
             HIP_TRY(kmp_launch_scan_multi(f, g.d_tables, g.words, g.n_unique, g.cshift, g.bmask, g.n_ones, g.ones, g.d_uid_first, g.d_uid_ids, c->stream));
