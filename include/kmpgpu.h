@@ -156,6 +156,8 @@ int  kmpgpu_load_frames(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t fil
 int  kmpgpu_load_frames_begin(kmpgpu_ctx *ctx, const uint8_t *file_bytes, uint64_t file_nbytes, const uint64_t *frame_off,
                               const uint32_t *frame_caplen, uint64_t n_frames, int tcp);
 int  kmpgpu_load_frames_finish(kmpgpu_ctx *ctx, uint64_t *n_payloads);
+/* Between _begin and _finish: wait until the upload alone is through (the copy engine is free for the next context's). */
+int  kmpgpu_load_frames_uploaded(kmpgpu_ctx *ctx);
 
 /* Size the context's device buffers ahead of time for arenas of up to arena_bytes / n_pkts payloads and, when frame_bytes != 0, for
  * kmpgpu_load_frames calls of up to frame_bytes of capture / n_frames frames: a streamed capture (openmp_task.c:126-186) loads batch

@@ -130,6 +130,7 @@ GPU_API = {
     "kmpgpu_load_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
     "kmpgpu_load_frames_begin": (C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, u32p, C.c_uint64, C.c_int]),
     "kmpgpu_load_frames_finish": (C.c_int, [C.c_void_p, u64p]),
+    "kmpgpu_load_frames_uploaded": (C.c_int, [C.c_void_p]),
     "kmpgpu_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
     "kmpgpu_load_frames": (C.c_int, [C.c_void_p, u8p, C.c_uint64, u64p, u32p, C.c_uint64, C.c_int, u64p]),
     "kmpgpu_arena_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p, C.c_void_p]),

@@ -40,6 +40,7 @@ typedef struct slot {
     int       state;                 /* 0 free, 1 filled (frame batches: 1 walked, 2 staged) */
 } slot;
 
+#define KMP_MAX_DEVICES 64
 typedef struct shared {
     pthread_mutex_t mu;
     pthread_cond_t  cv;
@@ -61,6 +62,9 @@ typedef struct shared {
     uint64_t        file_bytes;
     uint64_t        batch_bytes, cap_pkts;
     int             per_shard;       /* consumer threads (contexts) per GPU shard */
+    int             serial_uploads;  /* raw frames: an upload is enqueued only when the one before it on that device is through (default) */
+    pthread_mutex_t up_mu[KMP_MAX_DEVICES];
+    kmpgpu_ctx     *up_last[KMP_MAX_DEVICES];
 } shared;
 
 typedef struct consumer {
@@ -173,7 +177,14 @@ static void *consume(void *arg)
             slot *s = take_slot(me);
             const double tl0 = now_s();
             if (s) {
+                /* ONE upload at a time per device: two in flight (one per context's stream, or one per shard that shares the GPU) split the
+                 * link between them and both finish late -- 47 ms for the 1.56 GB capture, 41 ms with each upload enqueued when the one
+                 * before it is through (profiles/r03_end_to_end.txt).  The token is the context whose upload was enqueued last. */
+                pthread_mutex_lock(&sh->up_mu[device]);
+                if (sh->serial_uploads && sh->up_last[device] && kmpgpu_load_frames_uploaded(sh->up_last[device])) die_gpu("kmpgpu_load_frames_uploaded");
                 if (kmpgpu_load_frames_begin(ctx[turn], s->arena, s->used, s->off, s->len, s->n, sh->tcp)) die_gpu("kmpgpu_load_frames");
+                sh->up_last[device] = ctx[turn];
+                pthread_mutex_unlock(&sh->up_mu[device]);
                 pend[turn] = s;
             }
             /* then the batch begun before this one (the other context); at the end of the capture, whatever is still pending */
@@ -204,7 +215,12 @@ static void *consume(void *arg)
             if (!s) break;
             /* waits for this context's previous scan, uploads (the other contexts' work keeps running) */
             const double tl0 = now_s();
-            if (kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n)) die_gpu("kmpgpu_load_arena");
+            /* (one load at a time per device, as for the raw frames above: kmpgpu_load_arena returns when its upload and the index behind it
+             * are through; the scan that follows runs beside the other thread's upload) */
+            if (sh->serial_uploads) pthread_mutex_lock(&sh->up_mu[device]);
+            const int lrc = kmpgpu_load_arena(c, s->arena, s->used, s->off, s->len, s->n);
+            if (sh->serial_uploads) pthread_mutex_unlock(&sh->up_mu[device]);
+            if (lrc) die_gpu("kmpgpu_load_arena");
             me->payloads += s->n;
             me->load_s += now_s() - tl0;
             { kmpgpu_timing tt; if (kmpgpu_last_timing(c, &tt) == 0) me->h2d_ms += tt.h2d_ms; }
@@ -246,8 +262,9 @@ int main(int argc, char *argv[])
     kmp_batch_reader *rd = kmp_batch_open(argv[1], proto, errbuf);                                 /* openmp_task.c:104-108 */
     if (!rd) { fprintf(stderr, "error reading pcap file: %s\n", errbuf); exit(1); }
 
-    const int ndev = kmpgpu_device_count();
+    int ndev = kmpgpu_device_count();
     if (ndev <= 0) die_gpu("no MI355X device");
+    if (ndev > KMP_MAX_DEVICES) ndev = KMP_MAX_DEVICES;
 
     uint64_t batch_bytes = 64ull << 20;
     const char *env = getenv("KMPGPU_BATCH_BYTES");
@@ -271,6 +288,8 @@ int main(int argc, char *argv[])
     sh.pats = &pats; sh.ndev = ndev;
     sh.frames_mode = frames_mode; sh.tcp = proto == KMP_PROTO_TCP;
     sh.batch_bytes = batch_bytes; sh.cap_pkts = cap_pkts; sh.per_shard = per_shard;
+    { const char *e = getenv("KMPGPU_SERIAL_UPLOADS"); sh.serial_uploads = e ? atoi(e) != 0 : 1; }
+    for (int d = 0; d < KMP_MAX_DEVICES; d++) { pthread_mutex_init(&sh.up_mu[d], NULL); sh.up_last[d] = NULL; }
     sh.file = kmp_batch_file(rd, &sh.file_bytes);
     sh.pp = (const uint8_t **)malloc(sizeof(uint8_t *) * (pats.n ? pats.n : 1));
     for (uint32_t i = 0; i < pats.n; i++) sh.pp[i] = pats.blob + pats.off[i];

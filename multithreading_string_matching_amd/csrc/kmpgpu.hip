@@ -1129,6 +1129,15 @@ int kmpgpu_load_frames_begin(kmpgpu_ctx *c, const uint8_t *file_bytes, uint64_t 
     return KMPGPU_OK;
 }
 
+int kmpgpu_load_frames_uploaded(kmpgpu_ctx *c)
+{
+    if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames_uploaded: ctx is NULL");
+    if (!c->fr_pending || c->fr_n == 0) return KMPGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[1]));
+    return KMPGPU_OK;
+}
+
 int kmpgpu_load_frames_finish(kmpgpu_ctx *c, uint64_t *n_payloads)
 {
     if (!c) return fail(KMPGPU_EINVAL, "kmpgpu_load_frames: ctx is NULL");

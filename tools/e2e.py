@@ -23,9 +23,11 @@ planted = K.synth_count_planted(sp, n, L)
 runs = [("serial (host extraction)", ["serial", pcap, strings], {}),
         ("serial, device extraction", ["serial", pcap, strings], {"KMPGPU_DEVICE_EXTRACT": "1"}),
         ("openmp_task 1 (payload batches 64 MiB)", ["openmp_task", pcap, strings, "1"], {}),
+        ("openmp_task 1 (payload batches, loads overlapping)", ["openmp_task", pcap, strings, "1"], {"KMPGPU_SERIAL_UPLOADS": "0"}),
         ("openmp_task 1, raw frames 64 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1"}),
         ("openmp_task 1, raw frames 32 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1", "KMPGPU_BATCH_BYTES": str(32 << 20)}),
         ("openmp_task 1, raw frames 128 MiB", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1", "KMPGPU_BATCH_BYTES": str(128 << 20)}),
+        ("openmp_task 1, raw frames, uploads overlapping", ["openmp_task", pcap, strings, "1"], {"KMPGPU_DEVICE_EXTRACT": "1", "KMPGPU_SERIAL_UPLOADS": "0"}),
         ("openmp_task 2, raw frames 64 MiB", ["openmp_task", pcap, strings, "2"], {"KMPGPU_DEVICE_EXTRACT": "1"})]
 for rep in range(3):                        # second round: file in the page cache for sure
     for name, argv, env in runs:
