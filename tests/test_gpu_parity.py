@@ -1043,6 +1043,7 @@ def test_frame_batches_loaded_in_two_steps(fixture_counts, tokens):
                 break
             batches += 1
             ctx = ms[turn]._ctx
+            assert G.kmpgpu_load_frames_uploaded(ms[turn ^ 1]._ctx) == 0                 # one upload at a time (no load begun there: nothing to wait for)
             rc = G.kmpgpu_load_frames_begin(ctx, C.cast(base, _lib.u8p), nb.value, off.ctypes.data_as(_lib.u64p), cl.ctypes.data_as(_lib.u32p), n, 0)
             assert rc == 0, G.kmpgpu_last_error()
             assert G.kmpgpu_load_frames_begin(ctx, C.cast(base, _lib.u8p), nb.value, off.ctypes.data_as(_lib.u64p), cl.ctypes.data_as(_lib.u32p), n, 0) != 0   # begun twice
