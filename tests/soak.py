@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import multithreading_string_matching_amd as K
-from multithreading_string_matching_amd.matcher import (GpuMatcher, OPT_MODE, OPT_KERNEL, OPT_FUSED, OPT_DEPTH, OPT_BLOCKS_PER_CU,
+from multithreading_string_matching_amd.matcher import (GpuMatcher, OPT_MODE, OPT_KERNEL, OPT_FUSED, OPT_DEPTH, OPT_BLOCKS_PER_CU, OPT_FUSED_UNIT,
                                                         KERNEL_AUTO, KERNEL_FLAT, KERNEL_PACKED, KERNEL_GENERAL, MODE_FILTER, MODE_AUTOMATON)
 import oracle as O
 
@@ -37,7 +37,7 @@ while time.time() - t0 < budget:
                 if rng.random() < nul_p: b[i] = 0
         payloads.append(bytes(b))
     pats = []
-    for _ in range(rng.choice([1, 2, 3, 8, 20, 60])):
+    for _ in range(rng.choice([1, 2, 3, 8, 20, 60, 60, 300, 700])):           # 300, 700: classed groups of the fused pass (more than 256 distinct patterns), where the alphabet has that many
         mlen = rng.choice([1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 12, 16, 17, 20, 21, 40, 99])
         src = rng.choice(payloads)
         p = None
@@ -50,6 +50,7 @@ while time.time() - t0 < budget:
     arena = K.HostArena.from_payloads(payloads)
     want, _ = orc.count(arena.bytes, arena.off, arena.len, pats)
     m.set_option(OPT_DEPTH, rng.choice([0, 0, 2, 3, 4, 6])); m.set_option(OPT_BLOCKS_PER_CU, rng.choice([0, 0, 1, 3, 16]))
+    m.set_option(OPT_FUSED_UNIT, rng.choice([0, 0, 1024, 4096, 65536]))        # work units of the fused pass
     m.set_patterns(pats); m.load_arena(arena)
     for mode, kernel, fused in VARIANTS:
         m.set_option(OPT_MODE, mode); m.set_option(OPT_KERNEL, kernel); m.set_option(OPT_FUSED, fused)
